@@ -1,0 +1,170 @@
+/*
+ * mplattice.h -- C ABI of libmplattice.so: batched lattice planning kernels
+ * for AMD MI355X (gfx950).
+ *
+ * The reference planner (pure Python) has no FFI of its own; its boundary is
+ * the Python class surface that Planning/Interface/planner_interface.py:133-159
+ * calls.  Each entry point below names the reference method whose loop nest it
+ * replaces.  A batch holds B independent scenarios; scenario b of every array
+ * is the data one reference object would hold.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor) unless
+ *     the parameter is a small by-value struct; the caller owns all buffers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     only enqueue work, they never synchronise and never allocate;
+ *   - the return value is 0 on success or a negative MP_E_* code for argument
+ *     errors detected on the host (nothing was enqueued); per-scenario outcomes
+ *     are written to the `status` array on the device;
+ *   - all real numbers are IEEE double, indices are int32.
+ */
+#ifndef MPLATTICE_H
+#define MPLATTICE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_VERSION 100
+
+/* host-side return codes */
+#define MP_OK 0
+#define MP_E_BADARG (-1)      /* null pointer / non-positive size                 */
+#define MP_E_UNSUPPORTED (-2) /* size beyond what the kernel supports             */
+#define MP_E_LAUNCH (-3)      /* hipLaunch failed; see mp_last_error()            */
+
+/* per-scenario status written by the SL kernels */
+#define MP_SL_FOUND 1
+#define MP_SL_NOT_FOUND 0     /* path_planner.py:74-77 "Path not found!"          */
+#define MP_SL_E_EMPTY_EDGE (-2) /* a layer gap shorter than d_s with obstacles present:
+                                   the reference raises ValueError (min of empty) */
+#define MP_SL_E_CAPACITY (-3) /* more than MP_SL_K_CAP samples on one edge        */
+#define MP_SL_K_CAP 128
+
+/* per-scenario status written by mp_st_regions */
+#define MP_ST_OK 1
+#define MP_ST_E_CAPACITY (-3) /* more blocked intervals at one time layer than r_max */
+
+/* per-scenario status written by mp_refline_tables */
+#define MP_RL_OK 1
+#define MP_RL_E_INDEX (-1)    /* the reference raises IndexError (curve.py:57-65, 82-85) */
+#define MP_RL_E_CAPACITY (-3) /* more than m_max samples / n_knots_max knots      */
+
+/* Planning/DP_Path/path_planner.py:22-25 constants, overridable. */
+typedef struct mp_sl_params {
+    double d_s;          /* sample spacing along an edge (0.5)                    */
+    double w_d;          /* guide/smooth mix (0.5)                                */
+    double no_path_cost; /* 1e4: obstacle penalty = 3x, abort threshold = 10x     */
+    int32_t early_exit;  /* 1: stop relaxing a scenario at the first failing layer
+                            (reference behaviour); 0: relax every layer anyway    */
+    int32_t mid_l;       /* guide lane index, sl_map.py:20 int((n_l-1)/2)         */
+} mp_sl_params;
+
+/* One batch of SL lattices (Planning/DP_Path/sl_map.py:50-81, 86-109).
+ * Layer s of scenario b sits at arc length s_layers[b*n_s+s]; its lateral
+ * samples are l_map[b*l_bstride + s*l_rstride + l] (l_rstride = 0 when every
+ * layer shares one row).  Obstacles are struct-of-arrays, ob_stride slots per
+ * scenario of which the first n_ob[b] are used; ob_dist[b] is the single
+ * collision radius (sl_map.py:94,106). */
+typedef struct mp_sl_batch {
+    int32_t B, n_s, n_l, ob_stride;
+    const double *s_layers;  /* [B][n_s]                    */
+    const double *l_map;
+    int64_t l_bstride, l_rstride;
+    const double *ego_sl;    /* [B][2] (s, l) of the ego    */
+    const double *ob_s;      /* [B][ob_stride]              */
+    const double *ob_l;      /* [B][ob_stride]              */
+    const int32_t *n_ob;     /* [B]                         */
+    const double *ob_dist;   /* [B]                         */
+} mp_sl_batch;
+
+int mp_version(void);
+const char *mp_last_error(void);
+
+/* Replaces PathPlanner.find_path (path_planner.py:66-101) with cal_cost/get_path
+ * (:104-155) fused in: edge costs are produced and consumed on chip.
+ * Limits: n_l <= 256, n_s*n_l <= 65536.
+ * Outputs (cost_map, index_map, best_cost may be NULL):
+ *   cost_map  [B][n_s][n_l]  rows not relaxed stay 0      (path_planner.py:20)
+ *   index_map [B][n_s][n_l]  rows not relaxed stay -2, row 0 is -1 (:19-21,94)
+ *   path_idx  [B][n_s]       chosen lane per layer, -1 when not found (:79-87)
+ *   status    [B]            MP_SL_*
+ *   layers_done [B]          number of layers relaxed
+ *   best_cost [B]            cost of the chosen end node (NaN when not found) */
+int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
+               int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+               double *best_cost, void *stream);
+
+/* Replaces PathPlanner.cal_cost + get_path (path_planner.py:104-155) for every
+ * lattice edge: edge_cost[B][n_s][n_l(to)][n_l(from)]; layer 0 holds the ego
+ * edge in [..][to][0] and NaN elsewhere.  status as above (no FOUND/NOT_FOUND:
+ * MP_SL_FOUND means "ok"). */
+int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *params, double *edge_cost,
+                    int32_t *status, void *stream);
+
+/* Replaces PathPlanner.find_path/find_path_point (path_planner.py:66-101) over
+ * a materialised edge-cost tensor: layer-wise min-relaxation with first-minimum
+ * predecessor, abort test, end-node argmin and backtrack.  index_map is
+ * required (the backtrack reads it). Any n_l, n_s. */
+int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const double *edge_cost,
+             const mp_sl_params *params, double *cost_map, int32_t *index_map, int32_t *path_idx,
+             int32_t *status, int32_t *layers_done, double *best_cost, void *stream);
+
+/* Replaces SpeedPlanner.find_speed + find_speed_point + cal_cost
+ * (Planning/DP_Speed/speed_planner.py:57-162).  Scenario b uses an
+ * n_t x n_s[b] grid (n_s[b] <= n_s_max) with cell size ds x dt; blocked
+ * intervals of time layer i are s_down/s_up[b][i][0..n_reg[b][i]).
+ * Limits: n_t <= 64, n_s_max <= 1024, r_max <= 64.
+ * Outputs (cost, pre may be NULL):
+ *   cost [B][n_t][n_s_max], pre [B][n_t][n_s_max]   row 0 = 0 / -1 (st_map.py:86-91)
+ *   path_s_ind [B][n_t]  backtracked s indices, -1 padded; path_len [B] = end_i+1 */
+int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+             const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+             double speed_lim, double ds, double dt, double *cost, int32_t *pre,
+             int32_t *path_s_ind, int32_t *path_len, void *stream);
+
+/* Replaces STMap.add_obstacle + set_obstate (Planning/DP_Speed/st_map.py:24-60):
+ * for each time layer and obstacle, the s of the first and last path point
+ * closer than the obstacle radius (distance taken in Frenet (s,l) space).
+ * path_s/path_l [B][p_max] (first n_path[b] used); statics st_s/st_l/st_r
+ * [B][n_st_max]; dynamics dy_s/dy_l [B][n_dy_max][n_t], dy_r [B][n_dy_max].
+ * Outputs s_down/s_up [B][n_t][r_max], n_reg [B][n_t], status [B] MP_ST_*. */
+int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
+                  const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
+                  const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
+                  const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
+                  int32_t r_max, double *s_down, double *s_up, int32_t *n_reg, int32_t *status,
+                  void *stream);
+
+/* Replaces CartesianFrenetConverter.__init__ (Model/cartesian_frenet_conversion.py:11-27)
+ * and everything cartesian_to_frenet derives from the reference line alone:
+ * Curve.__init__ (Model/curve.py:13-38), the projection sample set
+ * (curve.py:120-123, calc_point_arr :40-73), get_s per sample (calc_arc_len
+ * :93-115, :175-186), heading and curvature per sample (cfc.py:37, :62-66).
+ * knots_x/knots_y [B][n_knots_max], first n_knots[b] used; vec [B] end slope;
+ * ego_xy [B][2] point whose projection fixes the Frenet origin; d_x = 0.5.
+ * Outputs, each [B][m_max] with M[b] valid: tab_x, tab_y, tab_s, tab_theta,
+ * tab_kappa; origin [B][2] = (rx_ori, ry_ori); status [B] MP_RL_*. */
+int mp_refline_tables(int32_t B, const double *knots_x, const double *knots_y,
+                      const int32_t *n_knots, int32_t n_knots_max, const double *vec,
+                      const double *ego_xy, double d_x, int32_t m_max, double *tab_x,
+                      double *tab_y, double *tab_s, double *tab_theta, double *tab_kappa,
+                      int32_t *M, double *origin, int32_t *status, void *stream);
+
+/* Replaces CartesianFrenetConverter.cartesian_to_frenet
+ * (Model/cartesian_frenet_conversion.py:32-53) + Curve.projection
+ * (Model/curve.py:117-126) for n_pts query points; point i belongs to scenario
+ * pt_scn[i] and reads that scenario's tables.  vx/vy/s_dt may all be NULL
+ * (order 0). */
+int mp_c2f_batch(int32_t n_pts, const double *px, const double *py, const double *vx,
+                 const double *vy, const int32_t *pt_scn, int32_t m_max, const double *tab_x,
+                 const double *tab_y, const double *tab_s, const double *tab_theta,
+                 const double *tab_kappa, const int32_t *M, double *s, double *l, double *s_dt,
+                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPLATTICE_H */

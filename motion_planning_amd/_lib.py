@@ -1,0 +1,74 @@
+"""ctypes binding of libmplattice.so (the HIP kernels behind a C ABI).
+
+The library is built in-tree by `make -C motion_planning_amd/csrc` (or
+__graft_entry__.build()).  There is no CPU fallback: if the shared object is
+missing or a GPU entry point is called without a GPU, the call raises.
+Signatures follow include/mplattice.h.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmplattice.so")
+
+MP_OK = 0
+MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY = 1, 0, -2, -3
+MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
+MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
+
+_vp = C.c_void_p
+
+
+class SlParams(C.Structure):
+    _fields_ = [("d_s", C.c_double), ("w_d", C.c_double), ("no_path_cost", C.c_double),
+                ("early_exit", C.c_int32), ("mid_l", C.c_int32)]
+
+
+class SlBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("n_s", C.c_int32), ("n_l", C.c_int32), ("ob_stride", C.c_int32),
+                ("s_layers", _vp), ("l_map", _vp), ("l_bstride", C.c_int64), ("l_rstride", C.c_int64),
+                ("ego_sl", _vp), ("ob_s", _vp), ("ob_l", _vp), ("n_ob", _vp), ("ob_dist", _vp)]
+
+
+# name -> (restype, argtypes); every symbol include/mplattice.h declares
+SIGNATURES = {
+    "mp_version": (C.c_int, []),
+    "mp_last_error": (C.c_char_p, []),
+    "mp_sl_plan": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 7),
+    "mp_sl_edge_cost": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams), _vp, _vp, _vp]),
+    "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, C.POINTER(SlParams)] + [_vp] * 7),
+    "mp_st_dp": (C.c_int, [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp] + [C.c_double] * 3 + [_vp] * 5),
+    "mp_st_regions": (C.c_int, [C.c_int32] * 2 + [_vp] * 3 + [C.c_int32] + [_vp] * 4 + [C.c_int32] + [_vp] * 4
+                      + [C.c_int32] * 2 + [_vp] * 5),
+    "mp_refline_tables": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_double, C.c_int32]
+                          + [_vp] * 9),
+    "mp_c2f_batch": (C.c_int, [C.c_int32] + [_vp] * 5 + [C.c_int32] + [_vp] * 10),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared object once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libmplattice.so is missing: build it with `make -C motion_planning_amd/csrc` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class MpError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != MP_OK:
+        raise MpError("%s failed (%d): %s" % (what, rc, lib().mp_last_error().decode()))

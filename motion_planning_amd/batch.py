@@ -1,0 +1,188 @@
+"""Batched planning entry points: B independent scenarios per call.
+
+Thin host layer over the C ABI (include/mplattice.h): tensors live in HBM as
+torch CUDA tensors (torch is used for device memory and streams only), the
+arithmetic is in libmplattice.so.  Every function returns torch tensors on the
+same device and enqueues on torch's current stream without synchronising.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SlBatch, SlParams, check, lib
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("motion_planning_amd needs a GPU: no CUDA/HIP device is visible "
+                           "(there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(a, dtype=torch.float64):
+    """numpy / list / tensor -> contiguous CUDA tensor of dtype."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=_dev(), dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(_dev()).contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def sl_params(d_s=0.5, w_d=0.5, no_path_cost=1e4, early_exit=True, mid_l=None, n_l=None):
+    """Planning/DP_Path/path_planner.py:22-25 constants; mid_l per sl_map.py:20."""
+    if mid_l is None:
+        mid_l = int((n_l - 1) / 2)
+    return SlParams(d_s, w_d, no_path_cost, int(bool(early_exit)), int(mid_l))
+
+
+class SLBatch:
+    """Device-resident SL lattices + obstacles of B scenarios (struct of arrays).
+
+    s_layers [B, n_s]; l_map [B, n_l] (one row shared by all layers) or
+    [B, n_s, n_l]; ego_sl [B, 2]; ob_s / ob_l [B, ob_stride]; n_ob [B]; ob_dist [B].
+    """
+
+    def __init__(self, s_layers, l_map, ego_sl, ob_s, ob_l, n_ob, ob_dist):
+        self.s_layers = to_dev(s_layers)
+        self.l_map = to_dev(l_map)
+        self.ego_sl = to_dev(ego_sl)
+        self.B, self.n_s = self.s_layers.shape
+        if self.l_map.dim() == 2:
+            self.n_l = self.l_map.shape[1]
+            self.l_bstride, self.l_rstride = self.n_l, 0
+        else:
+            assert self.l_map.shape[:2] == (self.B, self.n_s), "l_map must be [B, n_s, n_l]"
+            self.n_l = self.l_map.shape[2]
+            self.l_bstride, self.l_rstride = self.n_s * self.n_l, self.n_l
+        self.ob_s = to_dev(ob_s).reshape(self.B, -1)
+        self.ob_l = to_dev(ob_l).reshape(self.B, -1)
+        assert self.ob_s.shape == self.ob_l.shape
+        self.ob_stride = self.ob_s.shape[1]
+        if self.ob_stride == 0:  # keep the pointers valid
+            self.ob_s = torch.zeros((self.B, 1), dtype=torch.float64, device=self.ob_s.device)
+            self.ob_l = torch.zeros_like(self.ob_s)
+        self.n_ob = to_dev(n_ob, torch.int32)
+        self.ob_dist = to_dev(ob_dist)
+        assert self.ego_sl.shape == (self.B, 2) and self.n_ob.shape == (self.B,) and self.ob_dist.shape == (self.B,)
+        assert int(self.n_ob.max()) <= self.ob_stride if self.ob_stride else int(self.n_ob.max()) == 0
+
+    def c_struct(self):
+        return SlBatch(self.B, self.n_s, self.n_l, self.ob_stride, _p(self.s_layers), _p(self.l_map),
+                       self.l_bstride, self.l_rstride, _p(self.ego_sl), _p(self.ob_s), _p(self.ob_l),
+                       _p(self.n_ob), _p(self.ob_dist))
+
+    def n_edges(self):
+        """Lattice edges per scenario: n_l ego edges + (n_s-1)*n_l^2."""
+        return self.n_l + (self.n_s - 1) * self.n_l * self.n_l
+
+
+class SLPlanOut:
+    """Pre-allocated outputs of one SL plan call (reusable across calls)."""
+
+    def __init__(self, B, n_s, n_l, want_maps=True, device=None):
+        dev = device or _dev()
+        self.cost_map = torch.empty((B, n_s, n_l), dtype=torch.float64, device=dev) if want_maps else None
+        self.index_map = torch.empty((B, n_s, n_l), dtype=torch.int32, device=dev) if want_maps else None
+        self.path_idx = torch.empty((B, n_s), dtype=torch.int32, device=dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=dev)
+        self.layers_done = torch.empty(B, dtype=torch.int32, device=dev)
+        self.best_cost = torch.empty(B, dtype=torch.float64, device=dev)
+
+
+def sl_plan(batch, params=None, out=None, want_maps=True):
+    """Fused SL path DP (replaces PathPlanner.find_path, path_planner.py:66-101)."""
+    params = params or sl_params(n_l=batch.n_l)
+    out = out or SLPlanOut(batch.B, batch.n_s, batch.n_l, want_maps)
+    cs = batch.c_struct()
+    check(lib().mp_sl_plan(C.byref(cs), C.byref(params), _p(out.cost_map), _p(out.index_map), _p(out.path_idx),
+                           _p(out.status), _p(out.layers_done), _p(out.best_cost), _stream()), "mp_sl_plan")
+    return out
+
+
+def sl_edge_cost(batch, params=None):
+    """Every lattice edge cost (replaces PathPlanner.cal_cost, path_planner.py:104-130).
+
+    Returns (edge_cost [B, n_s, n_l(to), n_l(from)], status [B])."""
+    params = params or sl_params(n_l=batch.n_l)
+    dev = batch.s_layers.device
+    edge = torch.empty((batch.B, batch.n_s, batch.n_l, batch.n_l), dtype=torch.float64, device=dev)
+    status = torch.empty(batch.B, dtype=torch.int32, device=dev)
+    cs = batch.c_struct()
+    check(lib().mp_sl_edge_cost(C.byref(cs), C.byref(params), _p(edge), _p(status), _stream()), "mp_sl_edge_cost")
+    return edge, status
+
+
+def sl_dp(edge_cost, params, out=None):
+    """Layer-wise min-relaxation over materialised edge costs (path_planner.py:66-101)."""
+    B, n_s, n_l, _ = edge_cost.shape
+    out = out or SLPlanOut(B, n_s, n_l, True, edge_cost.device)
+    check(lib().mp_sl_dp(B, n_s, n_l, _p(edge_cost), C.byref(params), _p(out.cost_map), _p(out.index_map),
+                         _p(out.path_idx), _p(out.status), _p(out.layers_done), _p(out.best_cost), _stream()),
+          "mp_sl_dp")
+    return out
+
+
+def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tables=True, n_s_max=None):
+    """ST speed DP (replaces SpeedPlanner.find_speed, speed_planner.py:57-162).
+
+    n_s [B]; s_down / s_up [B, n_t, r_max]; n_reg [B, n_t]; cur_vel [B].
+    Returns dict(cost, pre, path_s_ind [B, n_t], path_len [B])."""
+    n_s = to_dev(n_s, torch.int32)
+    n_reg = to_dev(n_reg, torch.int32)
+    B, n_t = n_reg.shape
+    s_down = to_dev(s_down).reshape(B, n_t, -1)
+    s_up = to_dev(s_up).reshape(B, n_t, -1)
+    r_max = s_down.shape[2]
+    cur_vel = to_dev(cur_vel)
+    N = int(n_s_max if n_s_max is not None else n_s.max())
+    dev = n_s.device
+    cost = torch.empty((B, n_t, N), dtype=torch.float64, device=dev) if want_tables else None
+    pre = torch.empty((B, n_t, N), dtype=torch.int32, device=dev) if want_tables else None
+    idx = torch.empty((B, n_t), dtype=torch.int32, device=dev)
+    plen = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib().mp_st_dp(B, n_t, N, _p(n_s), _p(s_down), _p(s_up), _p(n_reg), r_max, _p(cur_vel),
+                         float(speed_lim), float(ds), float(dt), _p(cost), _p(pre), _p(idx), _p(plen),
+                         _stream()), "mp_st_dp")
+    return dict(cost=cost, pre=pre, path_s_ind=idx, path_len=plen)
+
+
+def st_regions(n_t, path_s, path_l, n_path, st_s, st_l, st_r, n_st, dy_s, dy_l, dy_r, n_dy, r_max):
+    """ST blocked intervals (replaces STMap.add_obstacle, st_map.py:24-60).
+
+    path_s / path_l [B, p_max]; statics [B, n_st_max]; dynamics dy_s / dy_l
+    [B, n_dy_max, n_t], dy_r [B, n_dy_max].  Returns (s_down, s_up [B, n_t, r_max],
+    n_reg [B, n_t], status [B])."""
+    path_s, path_l = to_dev(path_s), to_dev(path_l)
+    B, p_max = path_s.shape
+    n_path = to_dev(n_path, torch.int32)
+    def _2d(x, tail=()):
+        x = to_dev(x)
+        return x.reshape((B, -1) + tail) if x.numel() else x.new_zeros((B, 0) + tail)
+
+    st_s, st_l, st_r = (_2d(x) for x in (st_s, st_l, st_r))
+    n_st = to_dev(n_st, torch.int32)
+    n_st_max = st_s.shape[1]
+    dy_s, dy_l = (_2d(x, (n_t,)) for x in (dy_s, dy_l))
+    dy_r = _2d(dy_r)
+    n_dy = to_dev(n_dy, torch.int32)
+    n_dy_max = dy_r.shape[1]
+    dev = path_s.device
+    s_down = torch.zeros((B, n_t, r_max), dtype=torch.float64, device=dev)
+    s_up = torch.zeros((B, n_t, r_max), dtype=torch.float64, device=dev)
+    n_reg = torch.empty((B, n_t), dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib().mp_st_regions(B, n_t, _p(path_s), _p(path_l), _p(n_path), p_max,
+                              _p(st_s) if n_st_max else None, _p(st_l) if n_st_max else None,
+                              _p(st_r) if n_st_max else None, _p(n_st) if n_st_max else None, n_st_max,
+                              _p(dy_s) if n_dy_max else None, _p(dy_l) if n_dy_max else None,
+                              _p(dy_r) if n_dy_max else None, _p(n_dy) if n_dy_max else None, n_dy_max,
+                              r_max, _p(s_down), _p(s_up), _p(n_reg), _p(status), _stream()), "mp_st_regions")
+    return s_down, s_up, n_reg, status

@@ -1,0 +1,95 @@
+// Device-side helpers shared by the lattice kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/mplattice.h"
+
+#define MP_WAVE 64
+#define MP_INF (__builtin_huge_val())
+
+// ---- wave-level reductions (64 lanes, butterfly over __shfl_xor) ----------
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double o = __shfl_xor(v, m, MP_WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// First-minimum argmin: lower cost wins, equal costs keep the lower index.
+__device__ __forceinline__ void argmin_merge(double &c, int &i, double oc, int oi)
+{
+    bool take = (oc < c) | ((oc == c) & (oi < i));
+    c = take ? oc : c;
+    i = take ? oi : i;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void group_argmin(double &c, int &i)
+{
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) {
+        double oc = __shfl_xor(c, m, MP_WAVE);
+        int oi = __shfl_xor(i, m, MP_WAVE);
+        argmin_merge(c, i, oc, oi);
+    }
+}
+
+// ---- NumPy-order arithmetic ------------------------------------------------
+
+// np.sum of K copies of v, in NumPy's pairwise-summation order (K <= 128):
+// the guide cost of a straight edge is d_s * sum((l - mid)**2) over K equal
+// samples, and reproducing the order keeps exact ties between lanes exact.
+__device__ __forceinline__ double np_sum_const(double v, int K)
+{
+    if (K < 8) {
+        double r = 0.0;
+        for (int i = 0; i < K; ++i) r = __dadd_rn(r, v);
+        return r;
+    }
+    int blocks = K / 8; // each of the 8 accumulators receives `blocks` copies
+    double r = v;
+    for (int i = 1; i < blocks; ++i) r = __dadd_rn(r, v);
+    double p = __dadd_rn(r, r);
+    double q = __dadd_rn(p, p);
+    double res = __dadd_rn(q, q);
+    for (int i = blocks * 8; i < K; ++i) res = __dadd_rn(res, v);
+    return res;
+}
+
+// Sample count and positions of get_arange(t_st, t_en, dt) (Utils/tool.py:27-33):
+// np.arange gives n = ceil((t_en-t_st)/dt) values t_st + i*((t_st+dt)-t_st) and
+// t_en is appended when the last one differs.  Returns K (0 = empty); *n_out
+// receives n and *delta_out the fill step.  K > cap is reported as -1.
+__device__ __forceinline__ int arange_count(double t_st, double t_en, double dt, int cap,
+                                            int *n_out, double *delta_out)
+{
+    *n_out = 0;
+    *delta_out = 0.0;
+    if (__dadd_rn(t_st, dt) > t_en) return 0;
+    double q = __ddiv_rn(__dsub_rn(t_en, t_st), dt);
+    if (!(q <= (double)cap)) return -1;
+    int n = (int)ceil(q);
+    if (n < 1) return -1;
+    double delta = __dsub_rn(__dadd_rn(t_st, dt), t_st);
+    double last = (n == 1) ? t_st : __dadd_rn(t_st, __dmul_rn((double)(n - 1), delta));
+    if (n == 2) last = __dadd_rn(t_st, dt);
+    int K = n + (last != t_en ? 1 : 0);
+    *n_out = n;
+    *delta_out = delta;
+    return K > cap ? -1 : K;
+}
+
+__device__ __forceinline__ double arange_value(int k, int n, double t_st, double t_en, double dt,
+                                               double delta)
+{
+    if (k >= n) return t_en;
+    if (k == 0) return t_st;
+    if (k == 1) return __dadd_rn(t_st, dt);
+    return __dadd_rn(t_st, __dmul_rn((double)k, delta));
+}

@@ -1,0 +1,234 @@
+"""SL path DP on the GPU (through the C ABI) against the reference's golden
+outputs and against the CPU oracle on seeded random lattices."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from parity import assert_costs, assert_sl_parity, pad_obstacles
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, split=False, shared_row=False):
+    """Runs B scenarios; s_map/l_map [B, n_s, n_l]. Returns list of dicts (numpy)."""
+    from motion_planning_amd import batch as mb
+    s_map, l_map = np.asarray(s_map), np.asarray(l_map)
+    B, n_s, n_l = s_map.shape
+    ob_s, ob_l, n_ob = pad_obstacles(obs)
+    sb = mb.SLBatch(s_map[:, :, 0], l_map[:, 0, :] if shared_row else l_map, ego, ob_s, ob_l, n_ob, ob_dist)
+    prm = mb.sl_params(early_exit=early_exit, mid_l=mid_l)
+    if split:
+        edge, st = mb.sl_edge_cost(sb, prm)
+        assert (st.cpu().numpy() == 1).all()
+        out = mb.sl_dp(edge, prm)
+    else:
+        out = mb.sl_plan(sb, prm)
+    import torch
+    torch.cuda.synchronize()
+    res = []
+    for b in range(B):
+        res.append(dict(found=int(out.status[b]) == 1, status=int(out.status[b]),
+                        cost_map=out.cost_map[b].cpu().numpy(), index_map=out.index_map[b].cpu().numpy(),
+                        path_idx=out.path_idx[b].cpu().numpy(), layers_done=int(out.layers_done[b]),
+                        best_cost=float(out.best_cost[b])))
+    if split:
+        return res, edge.cpu().numpy()
+    return res
+
+
+def golden_case(g, case):
+    p = case + "_"
+    ref = dict(found=bool(g[p + "found"]), cost_map=g[p + "cost_map"], index_map=g[p + "index_map"],
+               path_idx=g[p + "path_idx"])
+    # rows the reference never relaxed stay at their initial values
+    done = int(np.sum(np.any(ref["index_map"] != -2, axis=1)))
+    ref["layers_done"] = done
+    inp = dict(s_map=g[p + "s_map"][None], l_map=g[p + "l_map"][None], mid_l=int(g[p + "mid_l"]),
+               ego=g[p + "ego"][None], obs=[g[p + "ob"]], ob_dist=np.array([float(g[p + "ob_dist"])]))
+    edge = g[p + "edge_cost"] if (p + "edge_cost") in g.files else None
+    return inp, ref, edge
+
+
+def sl_cases():
+    return [str(c) for c in load_golden("sl.npz")["cases"]]
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("case", sl_cases())
+def test_sl_golden(case, split):
+    g = load_golden("sl.npz")
+    inp, ref, edge = golden_case(g, case)
+    if split:
+        (r,), e = gpu_sl(**inp, split=True)
+        if edge is not None:
+            d = ref["layers_done"]
+            assert_costs(e[0, 0, :, 0], edge[0, :, 0])
+            assert_costs(e[0, 1:d], edge[1:d])
+    else:
+        (r,) = gpu_sl(**inp)
+    assert_sl_parity(r, ref, edge)
+    # untouched rows keep the reference's initial values
+    d = ref["layers_done"]
+    assert (r["cost_map"][d:] == 0).all() and (r["index_map"][d:] == -2).all()
+    assert (r["index_map"][0] == -1).all()
+    if not ref["found"]:
+        assert (r["path_idx"] == -1).all()
+
+
+def test_sl_pipeline_goldens():
+    g = load_golden("pipe.npz")
+    for case in [str(c) for c in g["cases"]]:
+        p = case + "_"
+        n_l = g[p + "l_map"].shape[1]
+        (r,) = gpu_sl(g[p + "s_map"][None], g[p + "l_map"][None], int((n_l - 1) / 2), g[p + "ego"][None],
+                      [g[p + "ob"]], np.array([float(g[p + "ob_dist"])]))
+        assert r["found"] == bool(g[p + "found"])
+        d = r["layers_done"]
+        assert_costs(r["cost_map"][:d], g[p + "cost_map"][:d])
+        assert np.array_equal(r["index_map"][:d], g[p + "index_map"][:d])
+        if r["found"]:
+            assert np.array_equal(r["path_idx"], g[p + "path_idx"])
+
+
+def random_batch(rng, B, n_s, n_l, gap, n_ob, r_lo, r_hi, s_spread=None, jitter=False):
+    s_layers = np.cumsum(np.full((B, n_s), gap), axis=1)
+    if jitter:
+        s_layers[:, -1] += rng.uniform(-0.4 * gap, 0.9 * gap, B)
+    l_row = np.linspace(-1.45, 1.45, n_l)
+    s_map = np.repeat(s_layers[:, :, None], n_l, axis=2)
+    l_map = np.broadcast_to(l_row, (B, n_s, n_l)).copy()
+    ego = np.stack([np.zeros(B), rng.uniform(-0.3, 0.3, B)], 1)
+    hi = s_spread or s_layers[0, -1]
+    obs = [np.stack([rng.uniform(0.5, hi, n_ob), rng.uniform(-2.5, 2.5, n_ob)], 1) for _ in range(B)]
+    ob_dist = rng.uniform(r_lo, r_hi, B)
+    return s_map, l_map, ego, obs, ob_dist
+
+
+RANDOM_SHAPES = [
+    # B, n_s, n_l, gap, n_ob, r_lo, r_hi, s_spread, jitter
+    (24, 6, 5, 8.0, 3, 0.5, 1.0, None, True),
+    (16, 12, 5, 8.0, 6, 0.3, 0.8, None, True),
+    (12, 8, 16, 8.0, 10, 0.3, 0.8, None, False),
+    (8, 10, 33, 1.5, 12, 0.2, 0.6, None, False),
+    (6, 12, 64, 1.5, 20, 0.1, 0.4, None, False),
+    (4, 9, 128, 1.5, 30, 0.1, 0.3, None, True),
+    (3, 5, 200, 3.0, 10, 0.2, 0.5, None, False),
+    (8, 6, 12, 8.0, 40, 0.4, 0.9, 12.0, False),    # many pairs per layer: mask path
+    (4, 4, 16, 8.0, 300, 0.8, 1.2, 10.0, False),   # pair list overflows its LDS capacity
+]
+
+
+@pytest.mark.parametrize("shape", RANDOM_SHAPES, ids=lambda s: "B%d_%dx%d_ob%d" % (s[0], s[1], s[2], s[4]))
+@pytest.mark.parametrize("early_exit", [True, False])
+def test_sl_random_vs_oracle(oracle, shape, early_exit):
+    B, n_s, n_l, gap, n_ob, r_lo, r_hi, spread, jitter = shape
+    rng = np.random.default_rng(1000 + n_s * n_l + n_ob)
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, gap, n_ob, r_lo, r_hi, spread, jitter)
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit)
+    res_split, edges = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, split=True)
+    res_row = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, shared_row=True)
+    n_found = 0
+    for b in range(B):
+        small = n_s * n_l * n_l <= 40000
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b],
+                                  no_early_exit=not early_exit, want_edges=small)
+        assert_sl_parity(res[b], ref, ref.get("edge_cost"))
+        n_found += ref["found"]
+        # fused == edge tensor + DP kernel == shared-row layout, bit for bit
+        for other in (res_split[b], res_row[b]):
+            assert np.array_equal(res[b]["cost_map"], other["cost_map"])
+            assert np.array_equal(res[b]["index_map"], other["index_map"])
+            assert np.array_equal(res[b]["path_idx"], other["path_idx"])
+            assert res[b]["status"] == other["status"]
+        if small:
+            d = ref["layers_done"]
+            assert_costs(edges[b, 0, :, 0], ref["edge_cost"][0, :, 0])
+            assert_costs(edges[b, 1:d], ref["edge_cost"][1:d])
+    print("found %d of %d" % (n_found, B))
+
+
+def test_sl_empty_edge_and_capacity_status():
+    from motion_planning_amd import _lib
+    s_map = np.array([[[8.0] * 5, [8.2] * 5]])            # second gap shorter than d_s
+    l_map = np.broadcast_to(np.linspace(-1.45, 1.45, 5), (1, 2, 5)).copy()
+    (r,) = gpu_sl(s_map, l_map, 2, np.zeros((1, 2)), [np.array([[3.0, 0.0]])], np.array([0.5]))
+    assert r["status"] == _lib.MP_SL_E_EMPTY_EDGE
+    s_map = np.array([[[80.0] * 5, [90.0] * 5]])          # 161 samples on the ego edge
+    (r,) = gpu_sl(s_map, l_map, 2, np.zeros((1, 2)), [np.array([[3.0, 0.0]])], np.array([0.5]))
+    assert r["status"] == _lib.MP_SL_E_CAPACITY
+    (r,) = gpu_sl(np.array([[[8.0] * 5, [8.2] * 5]]), l_map, 2, np.zeros((1, 2)), [np.zeros((0, 2))],
+                  np.array([0.0]))
+    assert r["status"] == _lib.MP_SL_FOUND                  # no obstacles: empty edge costs 0
+
+
+def test_sl_unsupported_size_is_an_error():
+    from motion_planning_amd import batch as mb, _lib
+    B, n_s, n_l = 1, 2, 300
+    sb = mb.SLBatch(np.array([[8.0, 16.0]]), np.linspace(-1, 1, n_l)[None], np.zeros((1, 2)),
+                    np.zeros((1, 1)), np.zeros((1, 1)), np.zeros(1, np.int32), np.zeros(1))
+    with pytest.raises(_lib.MpError):
+        mb.sl_plan(sb)
+    # the edge-tensor path takes any lattice width
+    edge, st = mb.sl_edge_cost(sb)
+    out = mb.sl_dp(edge, mb.sl_params(n_l=n_l))
+    assert int(out.status[0]) == 1
+
+
+def cfg3_batch(B, seed0=1000, n_s=64, n_l=128, n_ob=50):
+    """Batched SL workload: 64 layers x 128 lanes, 1.5 m layer gap, 50 obstacles."""
+    s_layers = np.broadcast_to(1.5 * (np.arange(n_s) + 1.0), (B, n_s)).copy()
+    l_row = np.broadcast_to(np.linspace(-1.45, 1.45, n_l), (B, n_l)).copy()
+    ego = np.zeros((B, 2))
+    ob_s = np.zeros((B, n_ob))
+    ob_l = np.zeros((B, n_ob))
+    ob_dist = np.zeros(B)
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + b))
+        ego[b, 1] = rng.uniform(-0.3, 0.3)
+        ob_s[b] = rng.uniform(2, 96, n_ob)
+        ob_l[b] = rng.uniform(-2.5, 2.5, n_ob)
+        ob_dist[b] = rng.uniform(0.3, 0.8)
+    return s_layers, l_row, ego, ob_s, ob_l, np.full(B, n_ob, np.int32), ob_dist
+
+
+def test_sl_cfg3_subset_vs_oracle_and_properties(oracle):
+    import torch
+    from motion_planning_amd import batch as mb
+    B = 4096
+    s_layers, l_row, ego, ob_s, ob_l, n_ob, ob_dist = cfg3_batch(B)
+    sb = mb.SLBatch(s_layers, l_row, ego, ob_s, ob_l, n_ob, ob_dist)
+    for early in (True, False):
+        out = mb.sl_plan(sb, mb.sl_params(early_exit=early, n_l=128))
+        out2 = mb.sl_plan(sb, mb.sl_params(early_exit=early, n_l=128))
+        torch.cuda.synchronize()
+        # run-to-run identical
+        assert torch.equal(out.cost_map, out2.cost_map) and torch.equal(out.index_map, out2.index_map)
+        status = out.status.cpu().numpy()
+        assert set(np.unique(status)) <= {0, 1}
+        idx = out.index_map.cpu().numpy()
+        cm = out.cost_map.cpu().numpy()
+        path = out.path_idx.cpu().numpy()
+        done = out.layers_done.cpu().numpy()
+        if not early:
+            assert (done == 64).all()
+        found = np.flatnonzero(status == 1)
+        for b in found[:200]:
+            # backtrack consistency and end node = first argmin of the last row
+            assert path[b, -1] == int(np.argmin(cm[b, -1]))
+            for s in range(63, 0, -1):
+                assert path[b, s - 1] == idx[b, s, path[b, s]]
+            assert float(out.best_cost[b]) == cm[b, -1].min()
+        for b in np.flatnonzero(status == 0)[:200]:
+            assert (path[b] == -1).all()
+            assert cm[b, done[b] - 1].min() > 1e5 if early else True
+        # a handful of full-size scenarios against the oracle
+        for b in list(found[:2]) + list(np.flatnonzero(status == 0)[:2]):
+            s_map = np.repeat(s_layers[b][:, None], 128, axis=1)
+            l_map = np.broadcast_to(l_row[b], (64, 128))
+            ref = oracle.sl_find_path(s_map, l_map, 63, ego[b], np.stack([ob_s[b], ob_l[b]], 1), ob_dist[b],
+                                      no_early_exit=not early)
+            got = dict(found=status[b] == 1, cost_map=cm[b], index_map=idx[b], path_idx=path[b],
+                       layers_done=done[b])
+            assert_sl_parity(got, ref)
+        print("cfg3 early_exit=%s: found %d / %d" % (early, len(found), B))

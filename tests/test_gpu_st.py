@@ -1,0 +1,164 @@
+"""ST speed DP and ST blocked intervals on the GPU (through the C ABI) against
+the reference's golden outputs (bit-exact) and the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+LIM = 25.0 * 5.0 / 18.0
+
+
+def st_cases():
+    return [str(c) for c in load_golden("st.npz")["cases"]]
+
+
+def test_st_golden_batch_bit_exact():
+    """All golden ST cases in ONE ragged batch (different n_s and region counts)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    g = load_golden("st.npz")
+    cases = st_cases()
+    B = len(cases)
+    n_s = np.array([int(g[c + "_n_s"]) for c in cases], dtype=np.int32)
+    r_max = max(g[c + "_down"].shape[1] for c in cases)
+    down = np.zeros((B, 11, r_max))
+    up = np.zeros((B, 11, r_max))
+    n_reg = np.zeros((B, 11), dtype=np.int32)
+    cur = np.zeros(B)
+    for b, c in enumerate(cases):
+        r = g[c + "_down"].shape[1]
+        down[b, :, :r] = g[c + "_down"]
+        up[b, :, :r] = g[c + "_up"]
+        n_reg[b] = g[c + "_n_reg"]
+        cur[b] = float(g[c + "_cur_vel"])
+    out = mb.st_dp(n_s, down, up, n_reg, cur, LIM)
+    torch.cuda.synchronize()
+    for b, c in enumerate(cases):
+        n = n_s[b]
+        assert np.array_equal(out["cost"][b, :, :n].cpu().numpy(), g[c + "_cost"]), c
+        assert np.array_equal(out["pre"][b, :, :n].cpu().numpy(), g[c + "_pre"]), c
+        plen = int(out["path_len"][b])
+        assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), g[c + "_path_s_ind"]), c
+        assert (out["path_s_ind"][b, plen:].cpu().numpy() == -1).all()
+        # padding cells keep the initial values
+        assert (out["cost"][b, :, n:].cpu().numpy() == 0).all() and (out["pre"][b, :, n:].cpu().numpy() == -1).all()
+
+
+@pytest.mark.parametrize("n_s_hi,B", [(29, 64), (101, 48), (230, 6)])
+def test_st_random_vs_oracle(oracle, n_s_hi, B):
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(n_s_hi)
+    n_t, r_max = 11, 6
+    n_s = rng.integers(max(3, n_s_hi // 3), n_s_hi + 1, B).astype(np.int32)
+    n_s[0] = n_s_hi
+    n_s[1] = 2 if B > 1 else n_s[1]
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(0, n_s_hi, (B, n_t, r_max))
+    up = down + rng.uniform(0, 8, (B, n_t, r_max))
+    cur = rng.uniform(0, 10, B)
+    out = mb.st_dp(n_s, down, up, n_reg, cur, LIM)
+    out_nt = mb.st_dp(n_s, down, up, n_reg, cur, LIM, want_tables=False)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
+        n = n_s[b]
+        assert np.array_equal(out["cost"][b, :, :n].cpu().numpy(), ref["cost"])
+        assert np.array_equal(out["pre"][b, :, :n].cpu().numpy(), ref["pre"])
+        plen = int(out["path_len"][b])
+        assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"])
+    assert torch.equal(out["path_s_ind"], out_nt["path_s_ind"]) and torch.equal(out["path_len"], out_nt["path_len"])
+
+
+def test_st_other_grid_steps(oracle):
+    """ds/dt other than the defaults go through the same tables."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(5)
+    B, n_t, n_s, r_max = 8, 9, 40, 3
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(0, 30, (B, n_t, r_max))
+    up = down + rng.uniform(0, 5, (B, n_t, r_max))
+    cur = rng.uniform(0, 10, B)
+    out = mb.st_dp(np.full(B, n_s, np.int32), down, up, n_reg, cur, 7.3, ds=0.7, dt=0.3)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = oracle.st_find_speed(n_t, n_s, down[b], up[b], n_reg[b], float(cur[b]), 7.3, ds=0.7, dt=0.3)
+        assert np.array_equal(out["cost"][b].cpu().numpy(), ref["cost"])
+        assert np.array_equal(out["pre"][b].cpu().numpy(), ref["pre"])
+
+
+def test_st_regions_pipeline_goldens():
+    import torch
+    from motion_planning_amd import batch as mb
+    g = load_golden("pipe.npz")
+    cases = [str(c) for c in g["cases"] if bool(g[str(c) + "_found"])]
+    B = len(cases)
+    n_t = 11
+    p_max = max(len(g[c + "_path_sl"]) for c in cases)
+    n_st_max = max(1, max(len(g[c + "_st_traj"]) for c in cases))
+    n_dy_max = max(1, max(len(g[c + "_dy_traj"]) for c in cases))
+    ps, pl = np.zeros((B, p_max)), np.zeros((B, p_max))
+    npath = np.zeros(B, np.int32)
+    st_s, st_l, st_r = (np.zeros((B, n_st_max)) for _ in range(3))
+    n_st = np.zeros(B, np.int32)
+    dy_s, dy_l = np.zeros((B, n_dy_max, n_t)), np.zeros((B, n_dy_max, n_t))
+    dy_r = np.zeros((B, n_dy_max))
+    n_dy = np.zeros(B, np.int32)
+    for b, c in enumerate(cases):
+        path = g[c + "_path_sl"]
+        npath[b] = len(path)
+        ps[b, :len(path)], pl[b, :len(path)] = path[:, 0], path[:, 1]
+        st = g[c + "_st_traj"]
+        n_st[b] = len(st)
+        st_s[b, :len(st)], st_l[b, :len(st)], st_r[b, :len(st)] = st[:, 0], st[:, 1], g[c + "_st_rad"]
+        dy = g[c + "_dy_traj"]
+        n_dy[b] = len(dy)
+        dy_s[b, :len(dy)], dy_l[b, :len(dy)], dy_r[b, :len(dy)] = dy[:, :, 0], dy[:, :, 1], g[c + "_dy_rad"]
+    r_max = 8
+    down, up, n_reg, status = mb.st_regions(n_t, ps, pl, npath, st_s, st_l, st_r, n_st, dy_s, dy_l, dy_r, n_dy, r_max)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 1).all()
+    for b, c in enumerate(cases):
+        want_n = g[c + "_st_n_reg"]
+        assert np.array_equal(n_reg[b].cpu().numpy(), want_n), c
+        for i in range(n_t):
+            assert np.array_equal(down[b, i, :want_n[i]].cpu().numpy(), g[c + "_st_down"][i, :want_n[i]])
+            assert np.array_equal(up[b, i, :want_n[i]].cpu().numpy(), g[c + "_st_up"][i, :want_n[i]])
+
+
+def test_st_regions_random_vs_oracle(oracle):
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(77)
+    B, n_t, p_max = 12, 11, 150
+    n_st_max, n_dy_max, r_max = 300, 40, 64
+    npath = rng.integers(1, p_max + 1, B).astype(np.int32)
+    ps = np.cumsum(np.full((B, p_max), 0.5), axis=1) - 0.5
+    pl = 0.8 * np.sin(ps / 7.0 + rng.uniform(0, 3, (B, 1)))
+    n_st = rng.integers(0, n_st_max + 1, B).astype(np.int32)
+    n_st[0], n_st[1] = 0, n_st_max
+    n_dy = rng.integers(0, n_dy_max + 1, B).astype(np.int32)
+    n_dy[0] = 0
+    st_s, st_l = rng.uniform(-5, 80, (B, n_st_max)), rng.uniform(-6, 6, (B, n_st_max))
+    st_r = rng.uniform(0.2, 1.5, (B, n_st_max))
+    dy_s = rng.uniform(-5, 80, (B, n_dy_max, 1)) + rng.uniform(-3, 3, (B, n_dy_max, 1)) * np.arange(n_t) * 0.5
+    dy_l = rng.uniform(-4, 4, (B, n_dy_max, 1)) + rng.uniform(-1, 1, (B, n_dy_max, 1)) * np.arange(n_t) * 0.5
+    dy_r = rng.uniform(0.2, 1.5, (B, n_dy_max))
+    down, up, n_reg, status = mb.st_regions(n_t, ps, pl, npath, st_s, st_l, st_r, n_st, dy_s, dy_l, dy_r, n_dy, r_max)
+    torch.cuda.synchronize()
+    for b in range(B):
+        path = np.stack([ps[b, :npath[b]], pl[b, :npath[b]]], 1)
+        st = [(np.array([st_s[b, o], st_l[b, o]]), st_r[b, o]) for o in range(n_st[b])]
+        dy = [(np.stack([dy_s[b, o], dy_l[b, o]], 1), dy_r[b, o]) for o in range(n_dy[b])]
+        rd, ru, rn = oracle.st_add_obstacle(n_t, path, st, dy)
+        if rn.max() > r_max:
+            assert int(status[b]) == -3
+            continue
+        assert int(status[b]) == 1
+        assert np.array_equal(n_reg[b].cpu().numpy(), rn)
+        for i in range(n_t):
+            assert np.array_equal(down[b, i, :rn[i]].cpu().numpy(), rd[i, :rn[i]])
+            assert np.array_equal(up[b, i, :rn[i]].cpu().numpy(), ru[i, :rn[i]])
