@@ -186,3 +186,60 @@ def st_regions(n_t, path_s, path_l, n_path, st_s, st_l, st_r, n_st, dy_s, dy_l, 
                               _p(dy_r) if n_dy_max else None, _p(n_dy) if n_dy_max else None, n_dy_max,
                               r_max, _p(s_down), _p(s_up), _p(n_reg), _p(status), _stream()), "mp_st_regions")
     return s_down, s_up, n_reg, status
+
+
+class RefLineTables:
+    """Per-scenario reference-line sample tables in HBM (output of refline_tables)."""
+
+    def __init__(self, B, m_max, device):
+        f = dict(dtype=torch.float64, device=device)
+        self.B, self.m_max = B, m_max
+        self.tab_x = torch.zeros((B, m_max), **f)
+        self.tab_y = torch.zeros((B, m_max), **f)
+        self.tab_s = torch.zeros((B, m_max), **f)
+        self.tab_theta = torch.zeros((B, m_max), **f)
+        self.tab_kappa = torch.zeros((B, m_max), **f)
+        self.M = torch.zeros(B, dtype=torch.int32, device=device)
+        self.origin = torch.zeros((B, 2), **f)
+        self.status = torch.zeros(B, dtype=torch.int32, device=device)
+
+
+def refline_tables(knots_x, knots_y, n_knots, vec, ego_xy, d_x=0.5, m_max=None):
+    """Reference-line tables (replaces CartesianFrenetConverter.__init__ and the
+    per-sample parts of cartesian_to_frenet, cartesian_frenet_conversion.py:11-70).
+
+    knots_x / knots_y [B, n_knots_max]; n_knots [B]; vec [B]; ego_xy [B, 2]."""
+    knots_x, knots_y = to_dev(knots_x), to_dev(knots_y)
+    B, n_knots_max = knots_x.shape
+    n_knots = to_dev(n_knots, torch.int32)
+    vec, ego_xy = to_dev(vec), to_dev(ego_xy)
+    if m_max is None:
+        span = float((knots_x.max(dim=1).values - knots_x.min(dim=1).values).max())
+        m_max = int(span / d_x) + 8
+    t = RefLineTables(B, m_max, knots_x.device)
+    check(lib().mp_refline_tables(B, _p(knots_x), _p(knots_y), _p(n_knots), n_knots_max, _p(vec), _p(ego_xy),
+                                  float(d_x), m_max, _p(t.tab_x), _p(t.tab_y), _p(t.tab_s), _p(t.tab_theta),
+                                  _p(t.tab_kappa), _p(t.M), _p(t.origin), _p(t.status), _stream()),
+          "mp_refline_tables")
+    return t
+
+
+def c2f(tables, px, py, pt_scn, vx=None, vy=None):
+    """Batched cartesian_to_frenet (cartesian_frenet_conversion.py:32-53).
+
+    px / py [n_pts]; pt_scn [n_pts] scenario of each point; with vx / vy also s_dt.
+    Returns (s, l) or (s, l, s_dt)."""
+    px, py = to_dev(px).reshape(-1), to_dev(py).reshape(-1)
+    pt_scn = to_dev(pt_scn, torch.int32).reshape(-1)
+    n = px.numel()
+    s = torch.empty(n, dtype=torch.float64, device=px.device)
+    l = torch.empty_like(s)
+    order1 = vx is not None
+    if order1:
+        vx, vy = to_dev(vx).reshape(-1), to_dev(vy).reshape(-1)
+    s_dt = torch.empty_like(s) if order1 else None
+    check(lib().mp_c2f_batch(n, _p(px), _p(py), _p(vx) if order1 else None, _p(vy) if order1 else None,
+                             _p(pt_scn), tables.m_max, _p(tables.tab_x), _p(tables.tab_y), _p(tables.tab_s),
+                             _p(tables.tab_theta), _p(tables.tab_kappa), _p(tables.M), _p(s), _p(l), _p(s_dt),
+                             _stream()), "mp_c2f_batch")
+    return (s, l, s_dt) if order1 else (s, l)

@@ -1,2 +1,363 @@
-// placeholder, filled in below
+// Reference-line tables and batched Cartesian->Frenet conversion for gfx950.
+//
+// Reference: Model/cartesian_frenet_conversion.py:11-70 on top of
+// Model/curve.py:13-186.  cartesian_to_frenet projects a point on the NEAREST
+// PRE-SAMPLED point of the reference spline (no refinement), so everything it
+// returns besides the distance is a function of the sample index alone.
+// mp_refline_tables therefore builds, once per scenario, the sample set and the
+// arc length / heading / curvature at every sample, following the reference's
+// own (quirky) evaluation rules:
+//   - the sample ordinates come from Curve.calc_point_arr, which switches
+//     spline segment only once a sample lies more than dt past the segment end;
+//   - heading and curvature come from the scalar Curve.calc_point (get_i);
+//   - arc length is the rectangle rule over end-inclusive sample sets, one
+//     piece per spline segment, added up in segment order.
+// mp_c2f_batch is then a nearest-sample search plus table look-ups.
+//
+// The whole file is compiled without floating-point contraction so that the
+// operation order written here (the reference's) is the order executed.
+#pragma clang fp contract(off)
 #include "mp_device.h"
+
+#define RL_SEG_CAP 128 // spline segments per reference line
+#define RL_ARC_CAP 128 // samples in one rectangle-rule piece
+
+// Model/curve.py:130-157 QuinticPoly coefficients.
+__device__ void quintic_coef(double xs, double vxs, double axs, double xe, double vxe, double axe, double T,
+                             double *a)
+{
+    a[0] = xs;
+    a[1] = vxs;
+    a[2] = axs / 2.0;
+    a[3] = 1.0 * (20 * xe - 20 * xs - (8 * vxe + 12 * vxs) * T - (3 * axs - axe) * T * T) / (2 * T * T * T);
+    a[4] = 1.0 * (30 * xs - 30 * xe + (14 * vxe + 16 * vxs) * T + (3 * axs - 2 * axe) * T * T) /
+           (2 * T * T * T * T);
+    a[5] = 1.0 * (12 * xe - 12 * xs - (6 * vxe + 6 * vxs) * T - (axs - axe) * T * T) /
+           (2 * T * T * T * T * T);
+}
+
+// Model/curve.py:159-173 calc_point (power form; powers by repeated multiply).
+__device__ __forceinline__ double quintic_eval(const double *a, double t, int order)
+{
+    const double t2 = t * t, t3 = t2 * t;
+    if (order == 0) return a[0] + a[1] * t + a[2] * t2 + a[3] * t3 + a[4] * (t2 * t2) + a[5] * (t2 * t3);
+    if (order == 1) return a[1] + 2 * a[2] * t + 3 * a[3] * t2 + 4 * a[4] * t3 + 5 * a[5] * (t2 * t2);
+    if (order == 2) return 2 * a[2] + 6 * a[3] * t + 12 * a[4] * t2 + 20 * a[5] * t3;
+    return 6 * a[3] + 24 * a[4] * t + 60 * a[5] * t2;
+}
+
+// Model/curve.py:80-91 get_i: first segment whose running end reaches t.
+__device__ __forceinline__ void curve_get_i(const double *T, int n, double t, int *ii, double *tt)
+{
+    double t_sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        t_sum += T[i];
+        if (t <= t_sum) {
+            *ii = i;
+            *tt = t - t_sum + T[i];
+            return;
+        }
+    }
+    *ii = n - 1;
+    *tt = t_sum;
+}
+
+// np.sum (pairwise order, n <= 128) over generated elements f(i).
+template <class F>
+__device__ __forceinline__ double np_sum_gen(int n, F f)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += f(i);
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f(j);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += f(i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += f(i);
+    return res;
+}
+
+// Model/curve.py:175-186 QuinticPoly.calc_arc_len for t0 <= t1; *bad is set
+// when the piece has more than RL_ARC_CAP samples.
+__device__ double quintic_arc_len(const double *a, double t0, double t1, double dt, int *bad)
+{
+    int n;
+    double delta;
+    const int K = arange_count(t0, t1, dt, RL_ARC_CAP, &n, &delta);
+    if (K < 0) { *bad = 1; return 0.0; }
+    if (K == 0) return 0.0;
+    double s = np_sum_gen(K, [&](int i) {
+        double d = quintic_eval(a, arange_value(i, n, t0, t1, dt, delta), 1);
+        return __dsqrt_rn(1 + d * d);
+    });
+    return 1 * dt * s;
+}
+
+struct RlDev {
+    int32_t n_knots_max, m_max;
+    const double *knots_x, *knots_y;
+    const int32_t *n_knots;
+    const double *vec, *ego_xy;
+    double d_x;
+    double *tab_x, *tab_y, *tab_s, *tab_theta, *tab_kappa;
+    int32_t *M;
+    double *origin;
+    int32_t *status;
+};
+
+// One workgroup per scenario.  Dynamic LDS: tsum[m_max] (double) seg[m_max] (int).
+__global__ void refline_tables_kernel(RlDev a)
+{
+    extern __shared__ double smem[];
+    __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], seg_full[RL_SEG_CAP];
+    __shared__ double vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
+    __shared__ double red_c[16];
+    __shared__ int red_i[16];
+    __shared__ double sc_d[8]; // t_max, delta, first piece, t_bios, st_t
+    __shared__ int sc_i[8];    // M, n, status, k_ori, st_i
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    double *tsum = smem;
+    int *seg = (int *)(smem + a.m_max);
+    const int npts = a.n_knots[b];
+    const int n = npts - 1;
+    const double *kx = a.knots_x + (size_t)b * a.n_knots_max;
+    const double *ky = a.knots_y + (size_t)b * a.n_knots_max;
+    const double dt = a.d_x;
+    double *tab_x = a.tab_x + (size_t)b * a.m_max, *tab_y = a.tab_y + (size_t)b * a.m_max;
+    double *tab_s = a.tab_s + (size_t)b * a.m_max, *tab_th = a.tab_theta + (size_t)b * a.m_max;
+    double *tab_kr = a.tab_kappa + (size_t)b * a.m_max;
+
+    if (n < 1 || n > RL_SEG_CAP || npts > a.n_knots_max) {
+        if (tid == 0) { a.status[b] = MP_RL_E_CAPACITY; a.M[b] = 0; }
+        return;
+    }
+    const double t_bios = kx[0];
+    // Curve.__init__ (curve.py:22-38)
+    for (int i = tid; i < n; i += nt) T[i] = kx[i + 1] - kx[i];
+    __syncthreads();
+    for (int i = tid; i <= n; i += nt)
+        vv[i] = (i == 0 || i == n) ? a.vec[b] : 1.0 * (ky[i + 1] - ky[i - 1]) / (T[i] + T[i - 1]);
+    __syncthreads();
+    for (int i = tid; i <= n; i += nt)
+        aa[i] = (i == 0 || i == n) ? 0.0 : 1.0 * (vv[i + 1] - vv[i - 1]) / (T[i] + T[i - 1]);
+    __syncthreads();
+    for (int i = tid; i < n; i += nt)
+        quintic_coef(ky[i], vv[i], aa[i], ky[i + 1], vv[i + 1], aa[i + 1], T[i], coef + 6 * i);
+    __syncthreads();
+    // projection sample set (curve.py:120-123) and the lagged segment walk of
+    // calc_point_arr (curve.py:43-66), sequential by nature
+    if (tid == 0) {
+        int st = MP_RL_OK;
+        const double t_max = np_sum_gen(n, [&](int i) { return T[i]; });
+        int na;
+        double delta;
+        int M = arange_count(0.0, t_max, dt, a.m_max, &na, &delta);
+        if (M < 0) { st = MP_RL_E_CAPACITY; M = 0; }
+        else if (M == 0) { st = MP_RL_E_INDEX; }
+        sc_d[0] = t_max;
+        sc_d[1] = delta;
+        sc_i[1] = na;
+        if (M > 0) {
+            // t_arr - t_bios of element 0 is (0 + t_bios) - t_bios
+            int i;
+            double tt;
+            curve_get_i(T, n, (0.0 + t_bios) - t_bios, &i, &tt);
+            double t_sum = np_sum_gen(i + 1, [&](int q) { return T[q]; });
+            for (int j = 0; j < M; ++j) {
+                const double tj = (arange_value(j, na, 0.0, t_max, dt, delta) + t_bios) - t_bios;
+                if (tj > t_sum + dt) {
+                    i += 1;
+                    if (i < n) t_sum += T[i];
+                    else { st = MP_RL_E_INDEX; M = 0; break; }
+                }
+                seg[j] = i;
+                tsum[j] = t_sum;
+            }
+        }
+        sc_i[0] = M;
+        sc_i[2] = st;
+    }
+    __syncthreads();
+    const int M = sc_i[0];
+    if (sc_i[2] != MP_RL_OK) {
+        if (tid == 0) { a.status[b] = sc_i[2]; a.M[b] = 0; }
+        return;
+    }
+    const double t_max = sc_d[0], delta = sc_d[1];
+    const int na = sc_i[1];
+    // ordinates, heading, curvature per sample; nearest sample to the ego point
+    const double ex = a.ego_xy[2 * b], ey = a.ego_xy[2 * b + 1];
+    double best = MP_INF;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < M; k += nt) {
+        const double x = arange_value(k, na, 0.0, t_max, dt, delta) + t_bios;
+        const int i = seg[k];
+        const double y = quintic_eval(coef + 6 * i, (x - t_bios) - tsum[k] + T[i], 0);
+        tab_x[k] = x;
+        tab_y[k] = y;
+        int ii;
+        double tt;
+        curve_get_i(T, n, x - t_bios, &ii, &tt);
+        const double dl = quintic_eval(coef + 6 * ii, tt, 1);
+        const double ddl = quintic_eval(coef + 6 * ii, tt, 2);
+        tab_th[k] = atan(dl);
+        tab_kr[k] = 1.0 * fabs(ddl) / pow(1 + dl * dl, 1.5);
+        const double dx = x - ex, dy = y - ey;
+        const double d = __dsqrt_rn(dx * dx + dy * dy);
+        if (d < best) { best = d; bi = k; }
+    }
+    group_argmin<MP_WAVE>(best, bi);
+    if ((tid & (MP_WAVE - 1)) == 0) { red_c[tid / MP_WAVE] = best; red_i[tid / MP_WAVE] = bi; }
+    __syncthreads();
+    int bad = 0;
+    if (tid == 0) {
+        for (int w = 1; w < (nt + MP_WAVE - 1) / MP_WAVE; ++w) argmin_merge(best, bi, red_c[w], red_i[w]);
+        sc_i[3] = bi;
+    }
+    __syncthreads();
+    const int k_ori = sc_i[3];
+    const double rx_ori = arange_value(k_ori, na, 0.0, t_max, dt, delta) + t_bios;
+    // get_s pieces shared by every sample (curve.py:93-110): the origin's
+    // segment from its local start to the segment end, and every full segment
+    const double t0 = rx_ori - t_bios;
+    int st_i;
+    double st_t;
+    curve_get_i(T, n, t0, &st_i, &st_t);
+    for (int i = tid; i < n; i += nt) seg_full[i] = quintic_arc_len(coef + 6 * i, 0, T[i], dt, &bad);
+    if (tid == 0) sc_d[2] = quintic_arc_len(coef + 6 * st_i, st_t, T[st_i], dt, &bad);
+    __syncthreads();
+    const double first_piece = sc_d[2];
+    for (int k = tid; k < M; k += nt) {
+        const double x = arange_value(k, na, 0.0, t_max, dt, delta) + t_bios;
+        const double t1 = x - t_bios;
+        double arc;
+        if (t0 > t1) arc = 0.0;
+        else {
+            int en_i;
+            double en_t;
+            curve_get_i(T, n, t1, &en_i, &en_t);
+            if (en_t > T[en_i]) en_t = T[en_i];
+            if (st_i == en_i) arc = quintic_arc_len(coef + 6 * st_i, st_t, en_t, dt, &bad);
+            else {
+                arc = first_piece;
+                for (int i = st_i + 1; i < en_i; ++i) arc += seg_full[i];
+                arc += quintic_arc_len(coef + 6 * en_i, 0, en_t, dt, &bad);
+            }
+        }
+        tab_s[k] = arc;
+    }
+    bad = __syncthreads_or(bad);
+    if (tid == 0) {
+        a.status[b] = bad ? MP_RL_E_CAPACITY : MP_RL_OK;
+        a.M[b] = bad ? 0 : M;
+        a.origin[2 * b] = rx_ori;
+        a.origin[2 * b + 1] = tab_y[k_ori];
+    }
+}
+
+struct C2fDev {
+    int32_t n_pts, m_max;
+    const double *px, *py, *vx, *vy;
+    const int32_t *pt_scn;
+    const double *tab_x, *tab_y, *tab_s, *tab_theta, *tab_kappa;
+    const int32_t *M;
+    double *s, *l, *s_dt;
+};
+
+// One thread per query point (cartesian_frenet_conversion.py:32-53).
+__global__ void c2f_kernel(C2fDev a)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pts) return;
+    const int b = a.pt_scn[p];
+    const int M = a.M[b];
+    const double x = a.px[p], y = a.py[p];
+    const double *tx = a.tab_x + (size_t)b * a.m_max, *ty = a.tab_y + (size_t)b * a.m_max;
+    if (M <= 0) {
+        const double nan = __builtin_nan("");
+        a.s[p] = nan;
+        a.l[p] = nan;
+        if (a.s_dt) a.s_dt[p] = nan;
+        return;
+    }
+    // Curve.projection + cal_dist_arr: first minimum of the sample distances
+    double best = MP_INF;
+    int k = 0;
+    for (int i = 0; i < M; ++i) {
+        const double dx = tx[i] - x, dy = ty[i] - y;
+        const double d = __dsqrt_rn(dx * dx + dy * dy);
+        if (d < best) { best = d; k = i; }
+    }
+    const double rx = tx[k], ry = ty[k];
+    const double th = a.tab_theta[(size_t)b * a.m_max + k];
+    const double dx = x - rx, dy = y - ry;
+    const double l_sign = (dy * cos(th) - dx * sin(th) > 0) ? 1.0 : -1.0;
+    const double l = l_sign * best;
+    a.s[p] = a.tab_s[(size_t)b * a.m_max + k];
+    a.l[p] = l;
+    if (a.s_dt) {
+        const double kr = a.tab_kappa[(size_t)b * a.m_max + k];
+        const double vx = a.vx[p], vy = a.vy[p];
+        const double vtheta = atan2(vy, vx);
+        const double speed = __dsqrt_rn(vx * vx + vy * vy);
+        a.s_dt[p] = speed * cos(vtheta - th) / (1 - kr * l);
+    }
+}
+
+// ---------------------------------------------------------------------------
+extern void mp_set_error(const char *fmt, ...);
+
+static int c2f_launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mp_set_error("%s: %s", what, hipGetErrorString(e));
+        return MP_E_LAUNCH;
+    }
+    return MP_OK;
+}
+
+extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double *knots_y,
+                                 const int32_t *n_knots, int32_t n_knots_max, const double *vec,
+                                 const double *ego_xy, double d_x, int32_t m_max, double *tab_x, double *tab_y,
+                                 double *tab_s, double *tab_theta, double *tab_kappa, int32_t *M, double *origin,
+                                 int32_t *status, void *stream)
+{
+    if (B <= 0 || n_knots_max < 2 || m_max <= 0 || !(d_x > 0)) { mp_set_error("bad sizes"); return MP_E_BADARG; }
+    if (!knots_x || !knots_y || !n_knots || !vec || !ego_xy || !tab_x || !tab_y || !tab_s || !tab_theta ||
+        !tab_kappa || !M || !origin || !status) {
+        mp_set_error("null array");
+        return MP_E_BADARG;
+    }
+    if (m_max > 4096) { mp_set_error("mp_refline_tables: m_max > 4096"); return MP_E_UNSUPPORTED; }
+    RlDev a{n_knots_max, m_max, knots_x, knots_y, n_knots, vec, ego_xy, d_x, tab_x, tab_y, tab_s, tab_theta,
+            tab_kappa, M, origin, status};
+    size_t lds = (size_t)m_max * (sizeof(double) + sizeof(int));
+    lds = (lds + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(m_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_refline_tables");
+}
+
+extern "C" int mp_c2f_batch(int32_t n_pts, const double *px, const double *py, const double *vx,
+                            const double *vy, const int32_t *pt_scn, int32_t m_max, const double *tab_x,
+                            const double *tab_y, const double *tab_s, const double *tab_theta,
+                            const double *tab_kappa, const int32_t *M, double *s, double *l, double *s_dt,
+                            void *stream)
+{
+    if (n_pts <= 0 || m_max <= 0) { mp_set_error("bad sizes"); return MP_E_BADARG; }
+    if (!px || !py || !pt_scn || !tab_x || !tab_y || !tab_s || !tab_theta || !tab_kappa || !M || !s || !l) {
+        mp_set_error("null array");
+        return MP_E_BADARG;
+    }
+    if (s_dt && (!vx || !vy)) { mp_set_error("s_dt requested without velocities"); return MP_E_BADARG; }
+    C2fDev a{n_pts, m_max, px, py, vx, vy, pt_scn, tab_x, tab_y, tab_s, tab_theta, tab_kappa, M, s, l, s_dt};
+    hipLaunchKernelGGL(c2f_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_c2f_batch");
+}
