@@ -10,6 +10,15 @@ pytestmark = pytest.mark.gpu
 LIM = 25.0 * 5.0 / 18.0
 
 
+def same(a, b, what=""):
+    """Bit-exact comparison with a short failure message."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = np.argwhere(a != b)
+    assert len(bad) == 0, "%s: %d of %d differ, first at %s: %r vs %r" % (
+        what, len(bad), a.size, bad[0].tolist(), a[tuple(bad[0])], b[tuple(bad[0])])
+
+
 def st_cases():
     return [str(c) for c in load_golden("st.npz")["cases"]]
 
@@ -37,8 +46,8 @@ def test_st_golden_batch_bit_exact():
     torch.cuda.synchronize()
     for b, c in enumerate(cases):
         n = n_s[b]
-        assert np.array_equal(out["cost"][b, :, :n].cpu().numpy(), g[c + "_cost"]), c
-        assert np.array_equal(out["pre"][b, :, :n].cpu().numpy(), g[c + "_pre"]), c
+        same(out["cost"][b, :, :n].cpu().numpy(), g[c + "_cost"], c + " cost")
+        same(out["pre"][b, :, :n].cpu().numpy(), g[c + "_pre"], c + " pre")
         plen = int(out["path_len"][b])
         assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), g[c + "_path_s_ind"]), c
         assert (out["path_s_ind"][b, plen:].cpu().numpy() == -1).all()
@@ -65,8 +74,8 @@ def test_st_random_vs_oracle(oracle, n_s_hi, B):
     for b in range(B):
         ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
         n = n_s[b]
-        assert np.array_equal(out["cost"][b, :, :n].cpu().numpy(), ref["cost"])
-        assert np.array_equal(out["pre"][b, :, :n].cpu().numpy(), ref["pre"])
+        same(out["cost"][b, :, :n].cpu().numpy(), ref["cost"], "cost[%d]" % b)
+        same(out["pre"][b, :, :n].cpu().numpy(), ref["pre"], "pre[%d]" % b)
         plen = int(out["path_len"][b])
         assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"])
     assert torch.equal(out["path_s_ind"], out_nt["path_s_ind"]) and torch.equal(out["path_len"], out_nt["path_len"])
@@ -86,8 +95,8 @@ def test_st_other_grid_steps(oracle):
     torch.cuda.synchronize()
     for b in range(B):
         ref = oracle.st_find_speed(n_t, n_s, down[b], up[b], n_reg[b], float(cur[b]), 7.3, ds=0.7, dt=0.3)
-        assert np.array_equal(out["cost"][b].cpu().numpy(), ref["cost"])
-        assert np.array_equal(out["pre"][b].cpu().numpy(), ref["pre"])
+        same(out["cost"][b].cpu().numpy(), ref["cost"], "cost[%d]" % b)
+        same(out["pre"][b].cpu().numpy(), ref["pre"], "pre[%d]" % b)
 
 
 def test_st_regions_pipeline_goldens():
