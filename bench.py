@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Benchmark: batched SL path DP + ST speed DP plans/sec on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic scenarios that
+already sit in HBM: the SL path DP over a 64-layer x 128-lane lattice with 50
+obstacles per scenario (every layer relaxed, no early abort) followed by the
+ST speed DP on a default ST lattice (11 time layers x 97 s cells, 5 moving
+blocked intervals per layer), and -- with more than one GPU -- one RCCL
+all-gather of the per-scenario results.  Scenarios are independent, so ranks
+take disjoint blocks of scenarios (weak scaling: 4096 per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+prints ONE JSON line (rank 0).  For N > 1 launch with torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_S, N_L, N_OB = 64, 128, 50
+ST_N_T, ST_N_S, ST_R = 11, 97, 5
+SPEED_LIM = 25.0 * 5.0 / 18.0
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+VALU_FP32_PEAK_TF = 157.3    # MI355X vector fp32 spec
+VALU_FP64_PEAK_TF = 78.6     # MI355X vector fp64 spec
+
+
+def make_scenarios(first_id, B):
+    """Synthetic batch: layers every 1.5 m up to 96 m, lanes linspace(-1.45, 1.45, 128),
+    ego l ~ U(-0.3, 0.3), 50 obstacles s ~ U(2, 96), l ~ U(-2.5, 2.5), one radius ~ U(0.3, 0.8)
+    per scenario; PCG64 seeded with 1000 + scenario id.  ST side: start speed ~ U(3, 8),
+    five blocked intervals (s0 + v*t, s0 + v*t + 3) with randomly shifted s0."""
+    s_layers = np.broadcast_to(1.5 * (np.arange(N_S) + 1.0), (B, N_S)).copy()
+    l_row = np.broadcast_to(np.linspace(-1.45, 1.45, N_L), (B, N_L)).copy()
+    ego = np.zeros((B, 2))
+    ob_s, ob_l = np.zeros((B, N_OB)), np.zeros((B, N_OB))
+    ob_dist = np.zeros(B)
+    cur_vel = np.zeros(B)
+    down = np.zeros((B, ST_N_T, ST_R))
+    base = np.array([(12, 2), (20, 0), (6, 4), (25, -1), (15, 1)], dtype=np.float64)
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(1000 + first_id + b))
+        ego[b, 1] = rng.uniform(-0.3, 0.3)
+        ob_s[b] = rng.uniform(2, 96, N_OB)
+        ob_l[b] = rng.uniform(-2.5, 2.5, N_OB)
+        ob_dist[b] = rng.uniform(0.3, 0.8)
+        cur_vel[b] = rng.uniform(3, 8)
+        s0 = base[:, 0] * (96.0 / 28.0) + rng.uniform(-4, 4, ST_R)
+        down[b] = s0[None, :] + base[None, :, 1] * 0.5 * np.arange(ST_N_T)[:, None]
+    up = down + 3.0
+    return dict(s_layers=s_layers, l_row=l_row, ego=ego, ob_s=ob_s, ob_l=ob_l,
+                n_ob=np.full(B, N_OB, np.int32), ob_dist=ob_dist, cur_vel=cur_vel, down=down, up=up,
+                n_reg=np.full((B, ST_N_T), ST_R, np.int32), st_n_s=np.full(B, ST_N_S, np.int32))
+
+
+def cpu_baseline(sc, n_sample, threads):
+    """The CPU oracle (a quirk-exact C restatement of the reference planner) on the
+    first n_sample scenarios of the same batch, `threads` scenarios at a time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+
+    def one(b):
+        s_map = np.repeat(sc["s_layers"][b][:, None], N_L, axis=1)
+        l_map = np.broadcast_to(sc["l_row"][b], (N_S, N_L))
+        ob = np.stack([sc["ob_s"][b], sc["ob_l"][b]], 1)
+        r = orc.sl_find_path(s_map, l_map, int((N_L - 1) / 2), sc["ego"][b], ob, sc["ob_dist"][b],
+                             no_early_exit=True)
+        orc.st_find_speed(ST_N_T, ST_N_S, sc["down"][b], sc["up"][b], sc["n_reg"][b], float(sc["cur_vel"][b]),
+                          SPEED_LIM)
+        return r["found"]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(n_sample)))
+    dt = time.perf_counter() - t0
+    return n_sample / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenarios", type=int, default=4096, help="scenarios per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="scenarios timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--early-exit", type=int, default=0, help="1 = stop a scenario at its first failing layer")
+    ap.add_argument("--maps", type=int, default=0, help="1 = also write cost_map/index_map/ST tables to HBM")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from motion_planning_amd import batch as mb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    B = args.scenarios
+    sc = make_scenarios(rank * B, B)
+    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
+    prm = mb.sl_params(early_exit=bool(args.early_exit), n_l=N_L)
+    out = mb.SLPlanOut(B, N_S, N_L, want_maps=bool(args.maps))
+    st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
+                 n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
+    row = N_S + 2 + ST_N_T + 1 + 2  # int32 words per scenario in the gathered record
+    packed = torch.empty((B, row), dtype=torch.int32, device="cuda")
+    gathered = torch.empty((world * B, row), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        mb.sl_plan(sb, prm, out)
+        if i is not None:
+            ev[i][1].record()
+        st = mb.st_dp(st_in["n_s"], st_in["s_down"], st_in["s_up"], st_in["n_reg"], st_in["cur_vel"], SPEED_LIM,
+                      want_tables=bool(args.maps), n_s_max=ST_N_S)
+        if i is not None:
+            ev[i][2].record()
+        if world > 1:
+            packed[:, :N_S] = out.path_idx
+            packed[:, N_S] = out.status
+            packed[:, N_S + 1] = out.layers_done
+            packed[:, N_S + 2:N_S + 2 + ST_N_T] = st["path_s_ind"]
+            packed[:, N_S + 2 + ST_N_T] = st["path_len"]
+            packed[:, N_S + 3 + ST_N_T:] = out.best_cost.view(torch.int32).view(B, 2)
+            dist.all_gather_into_tensor(gathered, packed)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    sl_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    st_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    layers = out.layers_done.cpu().numpy().astype(np.int64)
+    edges_launch = int(np.sum(N_L + (layers - 1) * N_L * N_L))
+    found_frac = float((out.status == 1).float().mean())
+    bad = int(((out.status != 1) & (out.status != 0)).sum())
+    assert bad == 0, "kernel reported %d scenarios with an error status" % bad
+    assert int(st["path_len"].min()) >= 2
+
+    if rank == 0:
+        plans_per_s = world * B * args.steps / elapsed
+        edges_per_s = edges_launch / (sl_ms * 1e-3)
+        k_samples = 4  # samples per edge at a 1.5 m layer gap and 0.5 m spacing
+        flop_edge = 45 + k_samples * (50 + 7 * N_OB)      # as-written reference arithmetic per edge
+        alg_bytes = 8.0 * edges_launch                    # 4 B written + 4 B read per edge if materialised
+        res = {
+            "metric": "SL+ST DP plans/sec (quintic lattice edges/sec in edges_per_sec)",
+            "value": plans_per_s, "unit": "plans/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batched SL path DP 4096 scenarios/GPU x (64 s-layers x 128 l-samples, "
+                                   "50 obstacles), every layer relaxed, + ST speed DP 11x97 with 5 blocked "
+                                   "intervals per layer; RCCL all-gather of results when n_gpus > 1",
+                       "scenarios_per_gpu": B, "n_s": N_S, "n_l": N_L, "n_ob": N_OB, "st_n_t": ST_N_T,
+                       "st_n_s": ST_N_S, "st_regions": ST_R, "early_exit": bool(args.early_exit),
+                       "maps_written": bool(args.maps), "parallelism": "scenario-sharded x%d" % world},
+            "edges_per_sec": edges_per_s * world, "edges_per_launch": edges_launch,
+            "sl_kernel_ms": sl_ms, "st_kernel_ms": st_ms, "found_fraction": found_frac,
+            "roofline": {"bound": "hbm", "kernel": "sl_plan_kernel (fused edge cost + DP relaxation)",
+                         "achieved": alg_bytes / (sl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes = 8 B/edge (edge cost written once and read once if "
+                                 "materialised); the fused kernel keeps edge costs on chip, so achieved can "
+                                 "exceed what HBM could deliver"},
+            "roofline_valu": {"bound": "valu", "achieved": flop_edge * edges_launch / (sl_ms * 1e-3) / 1e12,
+                              "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s", "flop_per_edge": flop_edge,
+                              "frac": flop_edge * edges_launch / (sl_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TF,
+                              "note": "reference as-written flop count per edge; the kernel is strength-"
+                                      "reduced (per-layer sums, pruned obstacle pairs) and runs in fp64"},
+        }
+        if args.cpu_sample > 0:
+            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            v, dt = cpu_baseline(sc, min(args.cpu_sample, B), threads)
+            res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
+                                   "sample": "first %d scenarios of the same batch (SL every layer + ST), "
+                                             "C oracle, %d threads, %.1f s" % (min(args.cpu_sample, B), threads, dt)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
