@@ -9,9 +9,9 @@
 //     w_d*d_s*sum_k (l_k - mid)^2 + (1-w_d)*d_s*sum_k (l'_k^2 + l''_k^2 + l'''_k^2)
 //     + 3*no_path_cost if any sample is closer than ob_dist to any obstacle.
 //
-// Because the sample abscissae are shared by all n_l^2 edges of a layer, the
-// sums over k collapse to per-layer constants (A = sum h0, Bq = sum h0^2,
-// H = sum h1^2+h2^2+h3^2) and, with u = l1 - mid, dl = l2 - l1,
+// Strength reduction.  The sample abscissae are shared by all n_l^2 edges of a
+// layer, so the sums over k collapse to per-layer constants (A = sum h0,
+// Bq = sum h0^2, H = sum h1^2+h2^2+h3^2) and, with u = l1 - mid, dl = l2 - l1,
 //     edge = g(u) + dl*(2*cG*A*u + dl*(cG*Bq + cS*H)) + penalty,
 // where g(u) = w_d*(d_s*np.sum(K copies of u^2)) is evaluated in NumPy's own
 // summation order so that straight edges (dl = 0) are bit-identical to the
@@ -19,12 +19,21 @@
 // looks at (sample, obstacle) pairs whose arc-length gap is below ob_dist;
 // those few pairs are compacted into LDS once per layer.
 //
+// Exact pruning.  edge >= cS*H*dl^2 (the guide part is a sum of squares), so a
+// predecessor j of target l2 can only win if
+//     min_j(cost_prev) + cS*H*dl^2 <= cost of a candidate already evaluated.
+// Each target therefore evaluates its nearest predecessor first and then walks
+// outwards only while dl^2 stays under that bound.  Because the reference
+// evaluates the quintic outside [0, T] on every layer but the first, H grows
+// like s^8 and the walk usually stops after a few lanes; results are identical
+// to visiting all n_l predecessors (the bound carries explicit rounding slack).
+//
 // All arithmetic is fp64: lattice choices must be index-exact and the
 // obstacle penalty (3e4) turns a single mis-rounded distance into a wrong path.
 #include "mp_device.h"
 
 #define SL_E_REG 8   // (sample, obstacle) pairs kept in registers on the fused path
-#define SL_E_CAP 256 // LDS capacity of the compacted pair list
+#define SL_E_CAP 128 // LDS capacity of the compacted pair list
 
 struct SlDev {
     mp_sl_batch in;
@@ -35,43 +44,54 @@ struct SlDev {
     int32_t *status;
     int32_t *layers_done;
     double *best_cost;
-    double *edge_cost; // K1 only
+    double *edge_cost; // edge-tensor kernel only
 };
 
 // Per-layer block-shared scalars.
 struct LayerSh {
     double A;      // sum_k h0_k
     double Q;      // cG*sum h0^2 + cS*sum(h1^2+h2^2+h3^2)
-    double delta;  // np.arange fill step
+    double cSH;    // cS*sum(h1^2+h2^2+h3^2): lower bound of edge/dl^2
+    int n_ent;     // compacted (sample, obstacle) pairs
+    int pad;
+};
+
+struct LayerGeom {
     int K;         // samples on every edge of the layer
     int n;         // np.arange length before the appended end point
-    int n_ent;     // compacted (sample, obstacle) pairs
+    double delta;  // np.arange fill step
     int bad;       // MP_SL_E_* raised by this layer, 0 = fine
 };
 
-// Samples of one layer: abscissae xk, basis h0 and the per-sample smoothness
-// term; then A and Q.  Block-cooperative; ends with a barrier.
-__device__ void layer_tables(LayerSh *sh, double *xk, double *h0k, double *qk, double p1s, double p2s,
-                             double d_s, double cG, double cS, int n_ob)
+__device__ __forceinline__ double wave_sum_f64(double v)
 {
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int n;
-        double delta;
-        int K = arange_count(p1s, p2s, d_s, MP_SL_K_CAP, &n, &delta);
-        sh->bad = 0;
-        if (K < 0) { sh->bad = MP_SL_E_CAPACITY; K = 0; }
-        if (K == 0 && n_ob > 0 && sh->bad == 0) sh->bad = MP_SL_E_EMPTY_EDGE;
-        sh->K = K;
-        sh->n = n;
-        sh->delta = delta;
-        sh->n_ent = 0;
-    }
-    __syncthreads();
-    const int K = sh->K;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, MP_WAVE);
+    return v;
+}
+
+// Sample count of one layer; every thread computes the same value.
+__device__ __forceinline__ LayerGeom layer_geom(double p1s, double p2s, double d_s, int n_ob)
+{
+    LayerGeom g;
+    g.K = arange_count(p1s, p2s, d_s, MP_SL_K_CAP, &g.n, &g.delta);
+    g.bad = 0;
+    if (g.K < 0) { g.bad = MP_SL_E_CAPACITY; g.K = 0; }
+    else if (g.K == 0 && n_ob > 0) g.bad = MP_SL_E_EMPTY_EDGE;
+    return g;
+}
+
+// Samples of one layer, by the first wave of the block: abscissae xk, basis
+// h0k, and the sums A, Q, cSH (fixed butterfly order, so every kernel that
+// calls this gets the same bits).  The caller synchronises afterwards.
+__device__ __forceinline__ void layer_tables(LayerSh *sh, double *xk, double *h0k, const LayerGeom &g,
+                                             double p1s, double p2s, double d_s, double cG, double cS)
+{
+    if (threadIdx.x >= MP_WAVE) return;
     const double T = p2s - p1s;
-    for (int k = tid; k < K; k += blockDim.x) {
-        double x = arange_value(k, sh->n, p1s, p2s, d_s, sh->delta);
+    double sa = 0.0, sb = 0.0, sq = 0.0;
+    for (int k = threadIdx.x; k < g.K; k += MP_WAVE) {
+        double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
         double tau = x / T;
         double t2 = tau * tau;
         double h0 = t2 * tau * (10.0 + tau * (-15.0 + 6.0 * tau));
@@ -81,32 +101,31 @@ __device__ void layer_tables(LayerSh *sh, double *xk, double *h0k, double *qk, d
         double h3 = 60.0 * (1.0 + tau * (-6.0 + 6.0 * tau)) / (T * T * T);
         xk[k] = x;
         h0k[k] = h0;
-        qk[k] = h1 * h1 + h2 * h2 + h3 * h3;
+        sa += h0;
+        sb += h0 * h0;
+        sq += h1 * h1 + h2 * h2 + h3 * h3;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double A = 0.0, Bq = 0.0, H = 0.0;
-        for (int k = 0; k < K; ++k) {
-            A += h0k[k];
-            Bq += h0k[k] * h0k[k];
-            H += qk[k];
-        }
-        sh->A = A;
-        sh->Q = cG * Bq + cS * H;
+    sa = wave_sum_f64(sa);
+    sb = wave_sum_f64(sb);
+    sq = wave_sum_f64(sq);
+    if (threadIdx.x == 0) {
+        sh->A = sa;
+        sh->cSH = cS * sq;
+        sh->Q = cG * sb + cS * sq;
+        sh->n_ent = 0;
     }
-    __syncthreads();
 }
 
-// Compacts the (sample k, obstacle o) pairs with |x_k - ob_s| < ob_dist for
-// obstacles [o_lo, o_hi) into LDS (arbitrary order; the collision test is an
-// OR).  sh->n_ent must be 0 on entry; ends with a barrier.  n_ent may exceed
-// SL_E_CAP: entries beyond the capacity are dropped and the caller re-chunks.
-__device__ void build_entries(LayerSh *sh, const double *xk, const double *h0k, double *e_h0, double *e_ol,
-                              double *e_ds2, const double *ob_s, const double *ob_l, int o_lo, int o_hi,
-                              double r2)
+// Compacts the (sample k, obstacle o) pairs with |x_k - ob_s| < ob_dist into
+// LDS (arbitrary order; the collision test is an OR).  sh->n_ent must be 0 on
+// entry; the caller synchronises afterwards.  n_ent may exceed SL_E_CAP:
+// entries beyond the capacity are dropped and callers fall back to testing
+// every pair directly.
+__device__ __forceinline__ void build_entries(LayerSh *sh, const double *xk, const double *h0k, int K,
+                                              double *e_h0, double *e_ol, double *e_ds2, const double *ob_s,
+                                              const double *ob_l, int n_ob, double r2)
 {
-    const int K = sh->K;
-    for (int o = o_lo + threadIdx.x; o < o_hi; o += blockDim.x) {
+    for (int o = threadIdx.x; o < n_ob; o += blockDim.x) {
         double os = ob_s[o], ol = ob_l[o];
         for (int k = 0; k < K; ++k) {
             double ds = xk[k] - os;
@@ -121,164 +140,167 @@ __device__ void build_entries(LayerSh *sh, const double *xk, const double *h0k, 
             }
         }
     }
-    __syncthreads();
 }
 
+// One collision test: sample at l1 + dl*h0 against an obstacle at lateral ol
+// whose squared arc-length gap is ds2.
+__device__ __forceinline__ bool pair_hit(double l1, double dl, double h0, double ol, double ds2, double r2)
+{
+    double ll = fma(dl, h0, l1);
+    double d = ll - ol;
+    return fma(d, d, ds2) < r2;
+}
+
+// Collision of one edge against everything.  NE >= 0: NE pairs in registers;
+// NE == -1: the LDS pair list; NE == -2: every (sample, obstacle) pair (the
+// list overflowed).
 template <int NE>
-struct EntReg {
+struct Collider {
     double h0[NE > 0 ? NE : 1], ol[NE > 0 ? NE : 1], ds2[NE > 0 ? NE : 1];
-    // loads entries [e0, e0+NE) of the LDS list, padding with never-hit entries
-    __device__ __forceinline__ void load(const double *e_h0, const double *e_ol, const double *e_ds2, int e0,
-                                         int n_ent)
+    const double *e_h0, *e_ol, *e_ds2, *xk, *h0k, *ob_s, *ob_l;
+    int n_ent, K, n_ob;
+    double r2;
+    __device__ __forceinline__ void init(const double *eh, const double *eo, const double *ed, int ne,
+                                         const double *xk_, const double *h0k_, int K_, const double *obs,
+                                         const double *obl, int nob, double r2_)
     {
+        e_h0 = eh; e_ol = eo; e_ds2 = ed; n_ent = ne;
+        xk = xk_; h0k = h0k_; K = K_; ob_s = obs; ob_l = obl; n_ob = nob; r2 = r2_;
+        if constexpr (NE > 0) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            bool ok = e0 + e < n_ent;
-            h0[e] = ok ? e_h0[e0 + e] : 0.0;
-            ol[e] = ok ? e_ol[e0 + e] : 0.0;
-            ds2[e] = ok ? e_ds2[e0 + e] : MP_INF;
+            for (int e = 0; e < NE; ++e) {
+                bool ok = e < ne; // pad with pairs that can never hit
+                h0[e] = ok ? eh[e] : 0.0;
+                ol[e] = ok ? eo[e] : 0.0;
+                ds2[e] = ok ? ed[e] : MP_INF;
+            }
         }
     }
-    __device__ __forceinline__ bool hit(double l1, double dl, double r2) const
+    __device__ __forceinline__ bool hit(double l1, double dl) const
     {
         bool h = false;
+        if constexpr (NE > 0) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            double ll = fma(dl, h0[e], l1);
-            double d = ll - ol[e];
-            double d2 = fma(d, d, ds2[e]);
-            h |= d2 < r2;
+            for (int e = 0; e < NE; ++e) h |= pair_hit(l1, dl, h0[e], ol[e], ds2[e], r2);
+        } else if constexpr (NE == -1) {
+            for (int e = 0; e < n_ent; ++e) h |= pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
+        } else if constexpr (NE == -2) {
+            for (int o = 0; o < n_ob; ++o) {
+                const double os = ob_s[o], olv = ob_l[o];
+                for (int k = 0; k < K; ++k) {
+                    double ds = xk[k] - os;
+                    double d2 = ds * ds;
+                    if (d2 < r2) h |= pair_hit(l1, dl, h0k[k], olv, d2, r2);
+                }
+            }
         }
         return h;
     }
 };
 
-// Source-side per-layer arrays in LDS (4 doubles per source lane).
-struct SrcSh {
-    double *l;    // lateral offset of the source node
-    double *g;    // straight-edge guide cost w_d*d_s*sum (l-mid)^2
-    double *ua;   // 2*cG*A*(l-mid)
-    double *cp;   // accumulated cost of the source node
-};
-
-__device__ __forceinline__ double edge_closed_form(double l2v, double l1, double g, double ua, double Q)
+// Straight-edge guide cost w_d*(d_s*np.sum(K copies of (l1-mid)^2)).
+__device__ __forceinline__ double guide_straight(double u, int K, double w_d, double d_s)
 {
-    double dl = l2v - l1;
+    return __dmul_rn(w_d, __dmul_rn(d_s, np_sum_const(__dmul_rn(u, u), K)));
+}
+
+// Closed-form edge cost without the obstacle penalty.
+__device__ __forceinline__ double edge_closed_form(double dl, double g, double ua, double Q)
+{
     double t = fma(dl, Q, ua);
     return fma(dl, t, g);
 }
 
-// Relaxes the targets owned by this thread for one layer.
-//   NE >= 0 : collision test fused in, NE entries in registers
-//   NE <  0 : collision bits come from the LDS mask
-template <int NE, int SJ>
-__device__ __forceinline__ void relax_layer(const SlDev &a, int b, int s, int n_src, const SrcSh &src,
-                                            const double *lrow, double Q, double r2, double pen,
-                                            const double *e_h0, const double *e_ol, const double *e_ds2,
-                                            int n_ent, const unsigned *mask, int mwords, double *cost_cur,
-                                            unsigned char *idx8)
+// Source-side per-layer arrays in LDS, 16 B per lane and array so that lanes
+// reading consecutive sources touch every bank once.
+struct SrcSh {
+    double2 *lc; // (lateral offset of the source node, its accumulated cost)
+    double2 *gu; // (straight-edge guide cost, 2*cG*A*(l - mid))
+};
+
+// Relaxes target l2 = threadIdx.x of layer s: nearest predecessor first, then
+// outward walks that stop once cS*H*dl^2 alone exceeds the best cost so far.
+template <int NE>
+__device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int n_src, const SrcSh &src,
+                                               const double *lcur_g, const LayerSh *sh, double m_prev,
+                                               double g_max, bool sorted, double pen, const Collider<NE> &col,
+                                               double *cost_cur, unsigned char *idx8)
 {
-    const int n_l = a.in.n_l;
-    const int sub = threadIdx.x % SJ;
-    const int TL = blockDim.x / SJ;
-    const int ch = (n_src + SJ - 1) / SJ;
-    const int j_lo = sub * ch;
-    const int j_hi = min(n_src, j_lo + ch);
-    EntReg<(NE > 0 ? NE : 0)> ent;
-    if constexpr (NE > 0) ent.load(e_h0, e_ol, e_ds2, 0, n_ent);
-    for (int l2 = threadIdx.x / SJ; l2 < n_l; l2 += TL) {
-        const double l2v = lrow[l2];
-        double best = MP_INF;
-        int bi = 0x7fffffff;
-        for (int j = j_lo; j < j_hi; ++j) {
-            const double l1 = src.l[j];
-            double e = edge_closed_form(l2v, l1, src.g[j], src.ua[j], Q);
-            bool hit;
-            if constexpr (NE > 0) hit = ent.hit(l1, l2v - l1, r2);
-            else if constexpr (NE == 0) hit = false;
-            else hit = (mask[l2 * mwords + (j >> 5)] >> (j & 31)) & 1u;
-            e += hit ? pen : 0.0;
-            double c = e + src.cp[j];
-            if (c < best) { best = c; bi = j; }
-        }
-        if (SJ > 1) group_argmin<SJ>(best, bi);
-        if (sub == 0) {
-            cost_cur[l2] = best;
-            int32_t pi = (s == 0) ? -1 : bi;
-            idx8[(size_t)s * n_l + l2] = (unsigned char)bi;
-            size_t o = ((size_t)b * a.in.n_s + s) * n_l + l2;
-            if (a.cost_map) a.cost_map[o] = best;
-            if (a.index_map) a.index_map[o] = pi;
-        }
+    const int n_l = a.in.n_l, l2 = threadIdx.x;
+    if (l2 >= n_l) return MP_INF;
+    const double l2v = lcur_g[l2];
+    const double Q = sh->Q, cSH = sh->cSH;
+    auto eval = [&](int j, double l1, double cp, double dl) {
+        const double2 gu = src.gu[j];
+        double e = edge_closed_form(dl, gu.x, gu.y, Q);
+        e += col.hit(l1, dl) ? pen : 0.0;
+        return e + cp;
+    };
+    const int j0 = min(l2, n_src - 1);
+    double2 lc = src.lc[j0];
+    double best = eval(j0, lc.x, lc.y, l2v - lc.x);
+    int bj = j0;
+    // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
+    // m_prev + cSH*dl^2 up to rounding, which the slack terms cover.  The bound
+    // needs Q/cSH to be moderate (error of the closed form relative to cSH*dl^2).
+    double w2 = MP_INF;
+    if (cSH > 0.0 && Q <= 1e5 * cSH) {
+        double gap = best - m_prev;
+        gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
+        w2 = gap / (cSH * (1.0 - 1e-9));
     }
-}
-
-// Sets mask bit (l2, j) for every edge of the layer that collides with one of
-// the entries currently in the LDS list (processed SL_E_REG at a time).
-template <int SJ>
-__device__ void mask_accumulate(int n_l, int n_src, const SrcSh &src, const double *lrow, double r2,
-                                const double *e_h0, const double *e_ol, const double *e_ds2, int n_ent,
-                                unsigned *mask, int mwords)
-{
-    const int sub = threadIdx.x % SJ;
-    const int TL = blockDim.x / SJ;
-    const int ch = (n_src + SJ - 1) / SJ;
-    const int j_lo = sub * ch;
-    const int j_hi = min(n_src, j_lo + ch);
-    for (int e0 = 0; e0 < n_ent; e0 += SL_E_REG) {
-        EntReg<SL_E_REG> ent;
-        ent.load(e_h0, e_ol, e_ds2, e0, n_ent);
-        for (int l2 = threadIdx.x / SJ; l2 < n_l; l2 += TL) {
-            const double l2v = lrow[l2];
-            for (int j = j_lo; j < j_hi; ++j) {
-                const double l1 = src.l[j];
-                if (ent.hit(l1, l2v - l1, r2)) atomicOr(&mask[l2 * mwords + (j >> 5)], 1u << (j & 31));
-            }
+    for (int j = j0 - 1; j >= 0; --j) {
+        lc = src.lc[j];
+        const double dl = l2v - lc.x;
+        if (dl * dl > w2) {
+            if (sorted && dl > 0.0) break; // sources further down are further away
+            continue;
         }
+        const double c = eval(j, lc.x, lc.y, dl);
+        if (c <= best) { best = c; bj = j; } // lower index wins ties
     }
+    for (int j = j0 + 1; j < n_src; ++j) {
+        lc = src.lc[j];
+        const double dl = l2v - lc.x;
+        if (dl * dl > w2) {
+            if (sorted && dl < 0.0) break;
+            continue;
+        }
+        const double c = eval(j, lc.x, lc.y, dl);
+        if (c < best) { best = c; bj = j; }
+    }
+    cost_cur[l2] = best;
+    idx8[(size_t)s * n_l + l2] = (unsigned char)bj;
+    const size_t o = ((size_t)b * a.in.n_s + s) * n_l + l2;
+    if (a.cost_map) a.cost_map[o] = best;
+    if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
+    return best;
 }
 
-__device__ __forceinline__ double block_min(double v, double *red)
-{
-    v = wave_min_f64(v);
-    const int wave = threadIdx.x / MP_WAVE, nw = (blockDim.x + MP_WAVE - 1) / MP_WAVE;
-    __syncthreads();
-    if ((threadIdx.x & (MP_WAVE - 1)) == 0) red[wave] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int w = 1; w < nw; ++w) r = red[w] < r ? red[w] : r;
-    return r;
-}
-
-// Fused SL plan: one workgroup per scenario walks the layers; edge costs never
-// leave the chip.  Dynamic LDS layout (doubles first):
-//   cost_cur[n_l] src.l[n_l] src.g[n_l] src.ua[n_l] src.cp[n_l] lrow[n_l]
-//   xk[K_CAP] h0k[K_CAP] qk[K_CAP] e_h0[E_CAP] e_ol[E_CAP] e_ds2[E_CAP] red[16]
-//   LayerSh | mask[n_l*mwords] u32 | idx8[n_s*n_l] u8
-template <int SJ>
+// Fused SL plan: one workgroup per scenario (one thread per lane of the lattice)
+// walks the layers; edge costs never leave the chip.  Dynamic LDS layout:
+//   cost_cur[n_lp] | lc[n_lp] double2 | gu[n_lp] double2 | xk[K_CAP] h0k[K_CAP]   (n_lp = n_l rounded up to even)
+//   e_h0[E_CAP] e_ol[E_CAP] e_ds2[E_CAP] | red_min[8] red_max[8] | LayerSh | idx8[n_s*n_l] u8
 __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int n_l = a.in.n_l, n_s = a.in.n_s;
-    const int mwords = (n_l + 31) / 32;
+    const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
+    const int n_lp = (n_l + 1) & ~1; // keeps the double2 arrays 16-byte aligned
     double *cost_cur = smem;
     SrcSh src;
-    src.l = cost_cur + n_l;
-    src.g = src.l + n_l;
-    src.ua = src.g + n_l;
-    src.cp = src.ua + n_l;
-    double *lrow = src.cp + n_l;
-    double *xk = lrow + n_l;
+    src.lc = (double2 *)(cost_cur + n_lp);
+    src.gu = src.lc + n_lp;
+    double *xk = (double *)(src.gu + n_lp);
     double *h0k = xk + MP_SL_K_CAP;
-    double *qk = h0k + MP_SL_K_CAP;
-    double *e_h0 = qk + MP_SL_K_CAP;
+    double *e_h0 = h0k + MP_SL_K_CAP;
     double *e_ol = e_h0 + SL_E_CAP;
     double *e_ds2 = e_ol + SL_E_CAP;
-    double *red = e_ds2 + SL_E_CAP;
-    LayerSh *sh = (LayerSh *)(red + 16);
-    unsigned *mask = (unsigned *)(sh + 1);
-    unsigned char *idx8 = (unsigned char *)(mask + (size_t)n_l * mwords);
+    double *red_min = e_ds2 + SL_E_CAP;
+    double *red_max = red_min + 8;
+    LayerSh *sh = (LayerSh *)(red_max + 8);
+    unsigned char *idx8 = (unsigned char *)(sh + 1);
 
     const double *s_layers = a.in.s_layers + (size_t)b * n_s;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
@@ -294,70 +316,72 @@ __global__ void sl_plan_kernel(SlDev a)
 
     int status = MP_SL_FOUND;
     int done = 0;
+    double m_prev = 0.0; // minimum accumulated cost over the previous layer
     for (int s = 0; s < n_s; ++s) {
         const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
         const double p2s = s_layers[s];
         const int n_src = (s == 0) ? 1 : n_l;
         const double *lprev_g = lbase + (size_t)(s == 0 ? n_s - 1 : s - 1) * a.in.l_rstride;
-        const double mid = lprev_g[mid_l];
-        layer_tables(sh, xk, h0k, qk, p1s, p2s, d_s, cG, cS, n_ob);
-        if (sh->bad) { status = sh->bad; break; }
-        const int K = sh->K;
-        const double A = sh->A, Q = sh->Q;
-        // source-side arrays; cost_cur still holds the previous layer's row
-        for (int j = tid; j < n_src; j += nt) {
-            double l1 = (s == 0) ? ego_l : lprev_g[j];
-            double u = l1 - mid;
-            src.l[j] = l1;
-            src.g[j] = __dmul_rn(w_d, __dmul_rn(d_s, np_sum_const(__dmul_rn(u, u), K)));
-            src.ua[j] = 2.0 * cG * A * u;
-            src.cp[j] = (s == 0) ? 0.0 : cost_cur[j];
-        }
         const double *lcur_g = lbase + (size_t)s * a.in.l_rstride;
-        for (int l = tid; l < n_l; l += nt) lrow[l] = lcur_g[l];
-        build_entries(sh, xk, h0k, e_h0, e_ol, e_ds2, ob_s, ob_l, 0, n_ob, r2); // barrier inside
-        const int n_ent = sh->n_ent;
-        if (n_ent <= SL_E_REG) {
-            switch (n_ent) {
-            case 0: relax_layer<0, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            case 1: relax_layer<1, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            case 2: relax_layer<2, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            case 3: relax_layer<3, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            case 4: relax_layer<4, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            case 5:
-            case 6: relax_layer<6, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            default: relax_layer<8, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8); break;
-            }
-        } else {
-            // general path: collision bits accumulated into the LDS mask, in
-            // obstacle chunks small enough for the pair list
-            for (int w = tid; w < n_l * mwords; w += nt) mask[w] = 0u;
-            __syncthreads();
-            if (n_ent <= SL_E_CAP) {
-                mask_accumulate<SJ>(n_l, n_src, src, lrow, r2, e_h0, e_ol, e_ds2, n_ent, mask, mwords);
-            } else {
-                const int oc = max(1, SL_E_CAP / K);
-                for (int o0 = 0; o0 < n_ob; o0 += oc) {
-                    __syncthreads();
-                    if (tid == 0) sh->n_ent = 0;
-                    __syncthreads();
-                    build_entries(sh, xk, h0k, e_h0, e_ol, e_ds2, ob_s, ob_l, o0, min(n_ob, o0 + oc), r2);
-                    mask_accumulate<SJ>(n_l, n_src, src, lrow, r2, e_h0, e_ol, e_ds2, sh->n_ent, mask, mwords);
-                }
-            }
-            __syncthreads();
-            relax_layer<-1, SJ>(a, b, s, n_src, src, lrow, Q, r2, pen, e_h0, e_ol, e_ds2, n_ent, mask, mwords, cost_cur, idx8);
-        }
+        const double mid = lprev_g[mid_l];
+        const LayerGeom geo = layer_geom(p1s, p2s, d_s, n_ob);
+        if (geo.bad) { status = geo.bad; break; }
+        layer_tables(sh, xk, h0k, geo, p1s, p2s, d_s, cG, cS);
         __syncthreads();
+        // source-side arrays (cost_cur still holds the previous layer's row),
+        // sortedness of the source row, largest straight-edge cost, pair list
+        const double A = sh->A;
+        int sorted_loc = 1;
+        double g_loc = 0.0;
+        for (int j = tid; j < n_src; j += nt) {
+            const double l1 = (s == 0) ? ego_l : lprev_g[j];
+            const double u = l1 - mid;
+            const double g = guide_straight(u, geo.K, w_d, d_s);
+            src.lc[j] = make_double2(l1, (s == 0) ? 0.0 : cost_cur[j]);
+            src.gu[j] = make_double2(g, 2.0 * cG * A * u);
+            g_loc = g > g_loc ? g : g_loc;
+            if (s > 0 && j > 0 && !(lprev_g[j - 1] <= l1)) sorted_loc = 0;
+        }
+        g_loc = -wave_min_f64(-g_loc);
+        if ((tid & (MP_WAVE - 1)) == 0) red_max[wave] = g_loc;
+        build_entries(sh, xk, h0k, geo.K, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r2);
+        const bool sorted = __syncthreads_and(sorted_loc) != 0;
+        double g_max = red_max[0];
+        for (int w = 1; w < nw; ++w) g_max = red_max[w] > g_max ? red_max[w] : g_max;
+        const int n_ent = sh->n_ent;
+        double best;
+#define SL_RELAX(NE)                                                                                     \
+    {                                                                                                    \
+        Collider<NE> col;                                                                                \
+        col.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);                        \
+        best = relax_target<NE>(a, b, s, n_src, src, lcur_g, sh, m_prev, g_max, sorted, pen, col,        \
+                                cost_cur, idx8);                                                         \
+    }
+        switch (n_ent) {
+        case 0: SL_RELAX(0) break;
+        case 1: SL_RELAX(1) break;
+        case 2: SL_RELAX(2) break;
+        case 3: SL_RELAX(3) break;
+        case 4: SL_RELAX(4) break;
+        case 5:
+        case 6: SL_RELAX(6) break;
+        case 7:
+        case 8: SL_RELAX(8) break;
+        default:
+            if (n_ent <= SL_E_CAP) SL_RELAX(-1) else SL_RELAX(-2)
+            break;
+        }
+#undef SL_RELAX
+        best = wave_min_f64(best);
+        if ((tid & (MP_WAVE - 1)) == 0) red_min[wave] = best;
+        __syncthreads();
+        double m = red_min[0];
+        for (int w = 1; w < nw; ++w) m = red_min[w] < m ? red_min[w] : m;
+        m_prev = m;
         done = s + 1;
-        if (s >= 1) {
-            double m = MP_INF;
-            for (int l = tid; l < n_l; l += nt) m = cost_cur[l] < m ? cost_cur[l] : m;
-            m = block_min(m, red);
-            if (m > abort_thr) {
-                if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
-                if (a.p.early_exit) break;
-            }
+        if (s >= 1 && m > abort_thr) {
+            if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
+            if (a.p.early_exit) break;
         }
     }
     __syncthreads();
@@ -397,11 +421,12 @@ __global__ void sl_plan_kernel(SlDev a)
     }
 }
 
-// K1: every edge cost of one (scenario, layer) per workgroup, written with the
-// source index fastest so that consecutive lanes store consecutive doubles.
+// Edge tensor: every edge cost of one (scenario, layer) per workgroup, written
+// with the source index fastest so that consecutive lanes store consecutive
+// doubles.  Same arithmetic as the fused kernel, bit for bit.
 __global__ void sl_edge_cost_kernel(SlDev a)
 {
-    __shared__ double xk[MP_SL_K_CAP], h0k[MP_SL_K_CAP], qk[MP_SL_K_CAP];
+    __shared__ double xk[MP_SL_K_CAP], h0k[MP_SL_K_CAP];
     __shared__ double e_h0[SL_E_CAP], e_ol[SL_E_CAP], e_ds2[SL_E_CAP];
     __shared__ LayerSh sh;
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -422,57 +447,51 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     const double *lcur_g = lbase + (size_t)s * a.in.l_rstride;
     const double mid = lprev_g[a.p.mid_l];
     double *out = a.edge_cost + ((size_t)b * n_s + s) * n_l * n_l;
-    layer_tables(&sh, xk, h0k, qk, p1s, p2s, d_s, cG, cS, n_ob);
-    if (sh.bad) {
-        if (tid == 0) atomicMin(&a.status[b], sh.bad);
+    const LayerGeom geo = layer_geom(p1s, p2s, d_s, n_ob);
+    if (geo.bad) {
+        if (tid == 0) atomicMin(&a.status[b], geo.bad);
         for (int e = tid; e < n_l * n_l; e += nt) out[e] = __builtin_nan("");
         return;
     }
-    const int K = sh.K;
+    layer_tables(&sh, xk, h0k, geo, p1s, p2s, d_s, cG, cS);
+    __syncthreads();
     const double A = sh.A, Q = sh.Q;
-    build_entries(&sh, xk, h0k, e_h0, e_ol, e_ds2, ob_s, ob_l, 0, n_ob, r2);
+    build_entries(&sh, xk, h0k, geo.K, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r2);
+    __syncthreads();
     const int n_ent = sh.n_ent;
+    Collider<-1> col_list;
+    Collider<-2> col_all;
+    col_list.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);
+    col_all.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);
     for (int e = tid; e < n_l * n_l; e += nt) {
         const int l2 = e / n_l, j = e - l2 * n_l;
         if (j >= n_src) { out[e] = __builtin_nan(""); continue; }
         const double l1 = (s == 0) ? a.in.ego_sl[2 * b + 1] : lprev_g[j];
-        const double l2v = lcur_g[l2];
         const double u = l1 - mid;
-        const double g = __dmul_rn(w_d, __dmul_rn(d_s, np_sum_const(__dmul_rn(u, u), K)));
-        const double ua = 2.0 * cG * A * u;
-        double c = edge_closed_form(l2v, l1, g, ua, Q);
-        const double dl = l2v - l1;
-        bool hit = false;
-        if (n_ent <= SL_E_CAP) {
-            for (int q = 0; q < n_ent; ++q) {
-                double ll = fma(dl, e_h0[q], l1);
-                double d = ll - e_ol[q];
-                hit |= fma(d, d, e_ds2[q]) < r2;
-            }
-        } else {
-            // pair list overflowed: test every (sample, obstacle) pair directly
-            for (int o = 0; o < n_ob; ++o) {
-                double os = ob_s[o], ol = ob_l[o];
-                for (int k = 0; k < K; ++k) {
-                    double ds = xk[k] - os;
-                    double ds2 = ds * ds;
-                    if (ds2 < r2) {
-                        double ll = fma(dl, h0k[k], l1);
-                        double d = ll - ol;
-                        hit |= fma(d, d, ds2) < r2;
-                    }
-                }
-            }
-        }
+        const double dl = lcur_g[l2] - l1;
+        double c = edge_closed_form(dl, guide_straight(u, geo.K, w_d, d_s), 2.0 * cG * A * u, Q);
+        const bool hit = n_ent <= SL_E_CAP ? col_list.hit(l1, dl) : col_all.hit(l1, dl);
         c += hit ? pen : 0.0;
         out[e] = c;
     }
 }
 
-// K2: layer-wise min-relaxation over a materialised edge-cost tensor.  One
-// workgroup per scenario; each wave owns target rows, its 64 lanes stride over
-// the sources (coalesced reads) and the row's first-minimum is found with a
-// wave-level shuffle argmin.  LDS: cost_prev[n_l] cost_cur[n_l] red[16].
+__device__ __forceinline__ double block_min(double v, double *red)
+{
+    v = wave_min_f64(v);
+    const int wave = threadIdx.x / MP_WAVE, nw = (blockDim.x + MP_WAVE - 1) / MP_WAVE;
+    __syncthreads();
+    if ((threadIdx.x & (MP_WAVE - 1)) == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; ++w) r = red[w] < r ? red[w] : r;
+    return r;
+}
+
+// DP relaxation over a materialised edge-cost tensor.  One workgroup per
+// scenario; each wave owns target rows, its 64 lanes stride over the sources
+// (coalesced reads) and the row's first-minimum is found with a wave-level
+// shuffle argmin.  LDS: cost_prev[n_l] cost_cur[n_l] red[16].
 __global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_params p, double *cost_map,
                              int32_t *index_map, int32_t *path_idx, int32_t *status_out,
                              int32_t *layers_done, double *best_cost)
@@ -568,9 +587,8 @@ extern void mp_set_error(const char *fmt, ...);
 
 static size_t sl_plan_lds_bytes(int n_s, int n_l)
 {
-    size_t d = (size_t)6 * n_l + 3 * MP_SL_K_CAP + 3 * SL_E_CAP + 16;
+    size_t d = (size_t)5 * ((n_l + 1) & ~1) + 2 * MP_SL_K_CAP + 3 * SL_E_CAP + 16;
     size_t bytes = d * sizeof(double) + sizeof(LayerSh);
-    bytes += (size_t)n_l * ((n_l + 31) / 32) * sizeof(unsigned);
     bytes += (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
@@ -625,17 +643,8 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.best_cost = best_cost;
     a.edge_cost = nullptr;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l);
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(batch->B);
-    if (n_l <= 8) {
-        hipLaunchKernelGGL(sl_plan_kernel<8>, grid, dim3(64), lds, st, a);
-    } else if (n_l <= 32) {
-        int threads = ((4 * n_l + 63) / 64) * 64;
-        hipLaunchKernelGGL(sl_plan_kernel<4>, grid, dim3(threads), lds, st, a);
-    } else {
-        int threads = ((n_l + 63) / 64) * 64;
-        hipLaunchKernelGGL(sl_plan_kernel<1>, grid, dim3(threads), lds, st, a);
-    }
+    const int threads = ((n_l + 63) / 64) * 64;
+    hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
     return launch_check("mp_sl_plan");
 }
 

@@ -26,49 +26,174 @@ struct StDev {
     int32_t *path_s_ind, *path_len;
 };
 
-// Obstacle cost of cell s against the blocked intervals of one time layer
-// (speed_planner.py:138-150), accumulated in interval order.
-__device__ __forceinline__ double st_ob_cost(double s, double front, const double *down, const double *up,
-                                             int R)
-{
-    double ob = 0.0;
-    for (int k = 0; k < R; ++k) {
-        const double dn = down[k], u = up[k];
-        double term = 0.0;
-        if (s >= dn && s <= u) {
-            term = 1e8;
-        } else if (s < dn && s >= __dsub_rn(dn, front)) {
-            double d = __dsub_rn(__dadd_rn(front, s), dn);
-            term = __dmul_rn(1e3, __dmul_rn(d, d));
-        } else if (s > u && s <= __dadd_rn(u, 25.0)) {
-            double d = __dsub_rn(__dadd_rn(25.0, s), u);
-            term = __dmul_rn(1e3, __dmul_rn(d, d));
+// Blocked intervals of one time layer as seen from one cell (arc length s).
+// speed_planner.py:144-150 adds, per interval and in order: 1e8 if the cell is
+// inside; else 1e3*(front+s-down)^2 if the interval starts ahead within the
+// speed-dependent look-ahead `front`; else 1e3*(25+s-up)^2 if it ended less
+// than 25 m behind.  Only the middle case depends on the edge, so each interval
+// is reduced to (dn, cst): the term is the front formula when s >= dn - front
+// and cst otherwise, with dn = +inf for intervals that are not ahead of the
+// cell (inf - front = inf, so the front test then never fires) and cst = the
+// inside / behind constant or 0.  Evaluating the terms in interval order with
+// the reference's own operations keeps the sum bit-identical.
+template <int RT>
+struct StCell {
+    double dn[RT > 0 ? RT : 1], cst[RT > 0 ? RT : 1];
+    bool monotone; // the obstacle cost cannot decrease as the edge speed grows
+
+    __device__ __forceinline__ static void classify(double s, double dnk, double uk, double *dn_out, double *cst_out)
+    {
+        double back = 0.0;
+        if (s > uk && s <= __dadd_rn(uk, 25.0)) {
+            double d = __dsub_rn(__dadd_rn(25.0, s), uk);
+            back = __dmul_rn(1e3, __dmul_rn(d, d));
         }
-        ob = __dadd_rn(ob, term);
+        if (s >= dnk && s <= uk) { *dn_out = MP_INF; *cst_out = 1e8; }
+        else if (s < dnk) { *dn_out = dnk; *cst_out = back; }
+        else { *dn_out = MP_INF; *cst_out = back; }
     }
-    return ob;
+
+    __device__ __forceinline__ void init(double s, const double *down, const double *up, int R)
+    {
+        monotone = true;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            if (k < R) {
+                classify(s, down[k], up[k], &dn[k], &cst[k]);
+                // an interval whose end precedes its start could trade a large
+                // "behind" constant for a small front term
+                if (dn[k] != MP_INF && cst[k] != 0.0) monotone = false;
+            } else { dn[k] = MP_INF; cst[k] = 0.0; } // padding adds exact zeros
+        }
+    }
+
+    __device__ __forceinline__ double ob(double s, double front) const
+    {
+        const double fs = __dadd_rn(front, s);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            const double d = __dsub_rn(fs, dn[k]);
+            const double t = (s >= __dsub_rn(dn[k], front)) ? __dmul_rn(1e3, __dmul_rn(d, d)) : cst[k];
+            acc = __dadd_rn(acc, t);
+        }
+        return acc;
+    }
+};
+
+// Any number of intervals: same terms, intervals re-read from LDS per edge.
+struct StCellLds {
+    const double *down, *up;
+    int R;
+    bool monotone;
+    __device__ __forceinline__ void init(double s, const double *down_, const double *up_, int R_)
+    {
+        down = down_; up = up_; R = R_;
+        monotone = true;
+        for (int k = 0; k < R; ++k) {
+            double dnk, c;
+            StCell<1>::classify(s, down[k], up[k], &dnk, &c);
+            if (dnk != MP_INF && c != 0.0) monotone = false;
+        }
+    }
+    __device__ __forceinline__ double ob(double s, double front) const
+    {
+        const double fs = __dadd_rn(front, s);
+        double acc = 0.0;
+        for (int k = 0; k < R; ++k) {
+            double dnk, c;
+            StCell<1>::classify(s, down[k], up[k], &dnk, &c);
+            const double d = __dsub_rn(fs, dnk);
+            const double t = (s >= __dsub_rn(dnk, front)) ? __dmul_rn(1e3, __dmul_rn(d, d)) : c;
+            acc = __dadd_rn(acc, t);
+        }
+        return acc;
+    }
+};
+
+struct StSh {
+    double *cost_prev, *cost_cur, *front, *speed, *acc, *jerk2, *jerk3, *down, *up;
+    short *pre16;
+};
+
+// All cells of time layer i >= 2 owned by this thread.
+//
+// Exact pruning: every term of the edge cost is non-negative and floating-point
+// addition is monotone, so predecessor p of cell j costs at least
+// (ob(d) + speed[d]) + cost_prev[p], d = j - p.  Each cell evaluates p = j
+// first (standing still) and walks p downwards, i.e. towards higher speeds; a
+// predecessor whose bound exceeds the best cost so far is skipped, and because
+// ob(d) and (above the speed limit) speed[d] never decrease with d, the walk
+// stops once (ob(d) + speed[d]) + min(cost_prev) exceeds it.  Skipped
+// predecessors are strictly worse, so cost, first-minimum index and every tie
+// are exactly those of the full scan.
+template <class CELL>
+__device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh, int i, int n_s, int N, int R,
+                                                 int d_lim, double m_prev, double *cost_g, int32_t *pre_g)
+{
+    const double ds = a.ds;
+    const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
+    const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
+    double m_loc = MP_INF;
+    for (int j = threadIdx.x; j < n_s; j += blockDim.x) {
+        const double s = __dmul_rn((double)j, ds);
+        CELL cell;
+        cell.init(s, sh.down, sh.up, R);
+        double best = MP_INF;
+        int bp = -1;
+        for (int p = j; p >= 0; --p) {
+            const int d = j - p;
+            const double cp = sh.cost_prev[p];
+            const double base = __dadd_rn(cell.ob(s, sh.front[d]), sh.speed[d]);
+            if (bp >= 0) {
+                if (cell.monotone && d >= d_lim && __dadd_rn(base, m_prev) > best) break;
+                if (__dadd_rn(base, cp) > best) continue;
+            }
+            const int pp = pre1[p];
+            const int n = d - (p - pp);
+            double jc;
+            if (i == 2) jc = sh.jerk2[n + (n_s - 1)];
+            else {
+                const int ppp = pre2[pp];
+                jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * (n_s - 1)];
+            }
+            const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + (n_s - 1)]), jc);
+            const double c = __dadd_rn(tot, cp);
+            if (bp < 0 || c <= best) { best = c; bp = p; } // lower index wins ties
+        }
+        sh.cost_cur[j] = best;
+        sh.pre16[(size_t)i * N + j] = (short)bp;
+        if (cost_g) cost_g[(size_t)i * N + j] = best;
+        if (pre_g) pre_g[(size_t)i * N + j] = bp;
+        m_loc = best < m_loc ? best : m_loc;
+    }
+    return m_loc;
 }
 
-// One workgroup per scenario.  Dynamic LDS (n = n_s of the scenario, N = n_s_max):
+// One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
 //   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
-//   down[r_max] up[r_max] last_col[n_t] | pre16[n_t][N] i16
+//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim
 __global__ void st_dp_kernel(StDev a)
 {
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int N = a.n_s_max, n_t = a.n_t, R_max = a.r_max;
     const int n_s = a.n_s[b];
-    double *cost_prev = smem;
-    double *cost_cur = cost_prev + N;
-    double *front = cost_cur + N;
-    double *speed = front + N;
-    double *acc = speed + N;       // index n + (n_s-1), n in [-(n_s-1), n_s-1]
-    double *jerk2 = acc + 2 * N;   // same index, layer i == 2
-    double *jerk3 = jerk2 + 2 * N; // index m + 2(n_s-1), layers i >= 3
-    double *down = jerk3 + 4 * N;
-    double *up = down + R_max;
-    double *last_col = up + R_max;
-    short *pre16 = (short *)(last_col + n_t);
+    const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
+    StSh sh;
+    sh.cost_prev = smem;
+    sh.cost_cur = sh.cost_prev + N;
+    sh.front = sh.cost_cur + N;
+    sh.speed = sh.front + N;
+    sh.acc = sh.speed + N;         // index n + (n_s-1), n in [-(n_s-1), n_s-1]
+    sh.jerk2 = sh.acc + 2 * N;     // same index, layer i == 2
+    sh.jerk3 = sh.jerk2 + 2 * N;   // index m + 2(n_s-1), layers i >= 3
+    sh.down = sh.jerk3 + 4 * N;
+    sh.up = sh.down + R_max;
+    double *last_col = sh.up + R_max;
+    double *red = last_col + n_t;
+    sh.pre16 = (short *)(red + 8);
+    int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
 
     const double ds = a.ds, dt = a.dt, lim = a.speed_lim;
     const double v0 = a.cur_vel[b];
@@ -76,103 +201,86 @@ __global__ void st_dp_kernel(StDev a)
     double *cost_g = a.cost ? a.cost + (size_t)b * n_t * N : nullptr;
     int32_t *pre_g = a.pre ? a.pre + (size_t)b * n_t * N : nullptr;
 
-    // tables (speed_planner.py:120-136, 151-160)
+    if (tid == 0) *d_lim_sh = n_s; // first d whose speed exceeds the limit
+    __syncthreads();
+    // tables (speed_planner.py:120-136, 151-160): terms that depend only on an
+    // integer difference, evaluated with the reference's operations
     for (int d = tid; d < n_s; d += nt) {
         double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)d), ds), dt);
-        front[d] = __dmul_rn(4.5, v);
+        sh.front[d] = __dmul_rn(4.5, v);
         double sc;
-        if (v > lim) sc = __dmul_rn(__dmul_rn(100.0, __dmul_rn(v, v)), dt);
-        else {
+        if (v > lim) {
+            sc = __dmul_rn(__dmul_rn(100.0, __dmul_rn(v, v)), dt);
+            double vm = d > 0 ? __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)(d - 1)), ds), dt) : 0.0;
+            if (d == 0 || !(vm > lim)) *d_lim_sh = d;
+        } else {
             double dv = __ddiv_rn(__dsub_rn(v, lim), lim);
             sc = __dmul_rn(__dmul_rn(-100.0, dv), dt);
         }
-        speed[d] = sc;
+        sh.speed[d] = sc;
     }
     for (int q = tid; q < 2 * n_s - 1; q += nt) {
         int n = q - (n_s - 1);
         double acv = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)n), ds), dt2);
-        acc[q] = __dmul_rn(__dmul_rn(acv, acv), dt);
+        sh.acc[q] = __dmul_rn(__dmul_rn(acv, acv), dt);
         double jk = __ddiv_rn(acv, dt);
-        jerk2[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
+        sh.jerk2[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
     }
     for (int q = tid; q < 4 * n_s - 3; q += nt) {
         int m = q - 2 * (n_s - 1);
         double jk = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)m), ds), dt3);
-        jerk3[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
+        sh.jerk3[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
     }
     // row 0: cost 0, pre_ind -1 (st_map.py:86-91)
     for (int j = tid; j < N; j += nt) {
-        cost_prev[j] = 0.0;
-        pre16[j] = -1;
+        sh.cost_prev[j] = 0.0;
+        sh.pre16[j] = -1;
         if (cost_g) cost_g[j] = 0.0;
         if (pre_g) pre_g[j] = -1;
     }
     if (tid == 0) last_col[0] = 0.0;
     __syncthreads();
+    const int d_lim = *d_lim_sh;
+    double m_prev = 0.0; // minimum of cost_prev
 
     for (int i = 1; i < n_t; ++i) {
         const int R = a.n_reg[(size_t)b * n_t + i];
         for (int k = tid; k < R; k += nt) {
-            down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
-            up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
+            sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
+            sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
         }
         __syncthreads();
-        const short *pre1 = pre16 + (size_t)(i - 1) * N;
-        const short *pre2 = pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
-        // Cells are handed out in pairs (t, n_s-1-t) and the two predecessor
-        // loops (j+1 iterations for cell j) run back to back in ONE loop of
-        // n_s+1 iterations, so every lane of a wave does the same amount of work.
-        for (int t = tid; 2 * t < n_s; t += nt) {
-            const int j1 = t, j2 = n_s - 1 - t;
-            const bool two = j2 != j1;
-            const double s1 = __dmul_rn((double)j1, ds), s2 = __dmul_rn((double)j2, ds);
-            double bestA = MP_INF, bestB = MP_INF;
-            int bpA = -1, bpB = -1;
-            if (i == 1) {
-                // only p_j = 0 (speed_planner.py:96-100)
-                for (int half = 0; half < (two ? 2 : 1); ++half) {
-                    const int j = half ? j2 : j1;
-                    double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)j), ds), dt);
-                    double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
-                    double jk = __ddiv_rn(ac, dt);
-                    double ob = st_ob_cost(half ? s2 : s1, front[j], down, up, R);
-                    double tot = __dadd_rn(__dadd_rn(__dadd_rn(ob, speed[j]), __dmul_rn(__dmul_rn(ac, ac), dt)),
-                                           __dmul_rn(__dmul_rn(jk, jk), dt));
-                    if (half) { bestB = tot; bpB = 0; } else { bestA = tot; bpA = 0; }
-                }
-            } else {
-                const int total = j1 + 1 + (two ? j2 + 1 : 0);
-                for (int q = 0; q < total; ++q) {
-                    const bool second = q > j1;
-                    const int j = second ? j2 : j1;
-                    const int p = second ? q - j1 - 1 : q;
-                    const int d = j - p;
-                    const int pp = pre1[p];
-                    const int n = d - (p - pp);
-                    double jc;
-                    if (i == 2) jc = jerk2[n + (n_s - 1)];
-                    else {
-                        const int ppp = pre2[pp];
-                        jc = jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * (n_s - 1)];
-                    }
-                    double ob = st_ob_cost(second ? s2 : s1, front[d], down, up, R);
-                    double tot = __dadd_rn(__dadd_rn(__dadd_rn(ob, speed[d]), acc[n + (n_s - 1)]), jc);
-                    double c = __dadd_rn(tot, cost_prev[p]);
-                    if (second) {
-                        if (bpB < 0 || c < bestB) { bestB = c; bpB = p; }
-                    } else {
-                        if (bpA < 0 || c < bestA) { bestA = c; bpA = p; }
-                    }
-                }
-            }
-            for (int half = 0; half < (two ? 2 : 1); ++half) {
-                const int j = half ? j2 : j1;
-                const double best = half ? bestB : bestA;
-                const int bp = half ? bpB : bpA;
-                cost_cur[j] = best;
-                pre16[(size_t)i * N + j] = (short)bp;
+        double m_loc = MP_INF;
+        if (i == 1) {
+            // only p_j = 0 (speed_planner.py:96-100)
+            for (int j = tid; j < n_s; j += nt) {
+                const double s = __dmul_rn((double)j, ds);
+                double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)j), ds), dt);
+                double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
+                double jk = __ddiv_rn(ac, dt);
+                StCellLds cell;
+                cell.init(s, sh.down, sh.up, R);
+                double ob = cell.ob(s, sh.front[j]);
+                double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed[j]), __dmul_rn(__dmul_rn(ac, ac), dt)),
+                                        __dmul_rn(__dmul_rn(jk, jk), dt));
+                sh.cost_cur[j] = best;
+                sh.pre16[(size_t)i * N + j] = 0;
                 if (cost_g) cost_g[(size_t)i * N + j] = best;
-                if (pre_g) pre_g[(size_t)i * N + j] = bp;
+                if (pre_g) pre_g[(size_t)i * N + j] = 0;
+                m_loc = best < m_loc ? best : m_loc;
+            }
+        } else {
+            switch (R) {
+            case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 1: m_loc = st_relax_layer<StCell<1>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 2: m_loc = st_relax_layer<StCell<2>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 3: m_loc = st_relax_layer<StCell<3>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 4: m_loc = st_relax_layer<StCell<4>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 5: m_loc = st_relax_layer<StCell<5>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 6: m_loc = st_relax_layer<StCell<6>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 7:
+            case 8: m_loc = st_relax_layer<StCell<8>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            default: m_loc = st_relax_layer<StCellLds>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
             }
         }
         // padding cells keep the initial values
@@ -180,13 +288,18 @@ __global__ void st_dp_kernel(StDev a)
             if (cost_g) cost_g[(size_t)i * N + j] = 0.0;
             if (pre_g) pre_g[(size_t)i * N + j] = -1;
         }
+        m_loc = wave_min_f64(m_loc);
+        if ((tid & (MP_WAVE - 1)) == 0) red[wave] = m_loc;
         __syncthreads();
-        for (int j = tid; j < n_s; j += nt) cost_prev[j] = cost_cur[j];
-        if (tid == 0) last_col[i] = cost_cur[n_s - 1];
+        for (int j = tid; j < n_s; j += nt) sh.cost_prev[j] = sh.cost_cur[j];
+        if (tid == 0) last_col[i] = sh.cost_cur[n_s - 1];
+        m_prev = red[0];
+        for (int w = 1; w < nw; ++w) m_prev = red[w] < m_prev ? red[w] : m_prev;
         __syncthreads();
     }
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
+        const double *cost_prev = sh.cost_prev;
         double min_i = last_col[1];
         int arg_i = 1;
         for (int i = 2; i < n_t; ++i)
@@ -203,7 +316,7 @@ __global__ void st_dp_kernel(StDev a)
         int j = end_j;
         out[end_i] = end_j;
         for (int i = end_i; i >= 1; --i) {
-            j = pre16[(size_t)i * N + j];
+            j = sh.pre16[(size_t)i * N + j];
             out[i - 1] = j;
         }
         a.path_len[b] = end_i + 1;
@@ -344,11 +457,11 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     }
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
-    size_t lds = ((size_t)12 * n_s_max + 2 * a.r_max + n_t) * sizeof(double) + (size_t)n_t * n_s_max * sizeof(short);
+    size_t lds = ((size_t)12 * n_s_max + 2 * a.r_max + n_t + 8) * sizeof(double) +
+                 ((size_t)n_t * n_s_max + 1) * sizeof(short) + 2 * sizeof(int);
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
-    int half = (n_s_max + 1) / 2;
-    int threads = half <= 64 ? 64 : (half <= 128 ? 128 : 256);
+    int threads = n_s_max <= 64 ? 64 : (n_s_max <= 128 ? 128 : 256);
     hipLaunchKernelGGL(st_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return st_launch_check("mp_st_dp");
 }
