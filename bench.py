@@ -100,7 +100,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from motion_planning_amd import batch as mb
+    from motion_planning_amd import batch as mb, dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,9 +108,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # MP_BENCH_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks
+    # share the card and the gather is staged through host memory)
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     B = args.scenarios
     sc = make_scenarios(rank * B, B)
@@ -119,9 +126,10 @@ def main():
     out = mb.SLPlanOut(B, N_S, N_L, want_maps=bool(args.maps))
     st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
                  n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
-    row = N_S + 2 + ST_N_T + 1 + 2  # int32 words per scenario in the gathered record
+    row = mdist.record_width(N_S, ST_N_T)  # int32 words per scenario in the gathered record
     packed = torch.empty((B, row), dtype=torch.int32, device="cuda")
-    gathered = torch.empty((world * B, row), dtype=torch.int32, device="cuda") if world > 1 else None
+    gdev = "cuda" if backend == "nccl" else "cpu"
+    gathered = torch.empty((world * B, row), dtype=torch.int32, device=gdev) if world > 1 else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -137,13 +145,9 @@ def main():
         if i is not None:
             ev[i][2].record()
         if world > 1:
-            packed[:, :N_S] = out.path_idx
-            packed[:, N_S] = out.status
-            packed[:, N_S + 1] = out.layers_done
-            packed[:, N_S + 2:N_S + 2 + ST_N_T] = st["path_s_ind"]
-            packed[:, N_S + 2 + ST_N_T] = st["path_len"]
-            packed[:, N_S + 3 + ST_N_T:] = out.best_cost.view(torch.int32).view(B, 2)
-            dist.all_gather_into_tensor(gathered, packed)
+            mdist.pack_results(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"],
+                               st["path_len"], out=packed)
+            mdist.gather_results_same_size(packed if backend == "nccl" else packed.cpu(), gathered)
         return st
 
     def fence():
@@ -174,6 +178,11 @@ def main():
     assert bad == 0, "kernel reported %d scenarios with an error status" % bad
     assert int(st["path_len"].min()) >= 2
 
+    if world > 1:
+        # every rank holds every scenario's record, in scenario order
+        u = mdist.unpack_results(gathered[rank * B:(rank + 1) * B].to("cuda"), N_S, ST_N_T)
+        assert torch.equal(u["path_idx"], out.path_idx) and torch.equal(u["st_path"], st["path_s_ind"])
+        assert int((mdist.unpack_results(gathered, N_S, ST_N_T)["st_len"] >= 2).sum()) == world * B
     if rank == 0:
         plans_per_s = world * B * args.steps / elapsed
         edges_per_s = edges_launch / (sl_ms * 1e-3)
