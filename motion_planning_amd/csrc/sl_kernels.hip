@@ -47,98 +47,98 @@ struct SlDev {
     double *edge_cost; // edge-tensor kernel only
 };
 
-// Per-layer block-shared scalars.
-struct LayerSh {
+struct LayerGeom {
+    int K;         // samples on every edge of the layer (negative: MP_SL_E_* code)
+    int n;         // np.arange length before the appended end point
+    double delta;  // np.arange fill step
+};
+
+// Per-layer constants of the closed-form edge cost.
+struct LayerConst {
     double A;      // sum_k h0_k
     double Q;      // cG*sum h0^2 + cS*sum(h1^2+h2^2+h3^2)
     double cSH;    // cS*sum(h1^2+h2^2+h3^2): lower bound of edge/dl^2
-    int n_ent;     // compacted (sample, obstacle) pairs
-    int pad;
 };
 
-struct LayerGeom {
-    int K;         // samples on every edge of the layer
-    int n;         // np.arange length before the appended end point
-    double delta;  // np.arange fill step
-    int bad;       // MP_SL_E_* raised by this layer, 0 = fine
-};
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, MP_WAVE);
-    return v;
-}
-
-// Sample count of one layer; every thread computes the same value.
+// Sample count of one layer.
 __device__ __forceinline__ LayerGeom layer_geom(double p1s, double p2s, double d_s, int n_ob)
 {
     LayerGeom g;
     g.K = arange_count(p1s, p2s, d_s, MP_SL_K_CAP, &g.n, &g.delta);
-    g.bad = 0;
-    if (g.K < 0) { g.bad = MP_SL_E_CAPACITY; g.K = 0; }
-    else if (g.K == 0 && n_ob > 0) g.bad = MP_SL_E_EMPTY_EDGE;
+    if (g.K < 0) g.K = MP_SL_E_CAPACITY;
+    else if (g.K == 0 && n_ob > 0) g.K = MP_SL_E_EMPTY_EDGE;
     return g;
 }
 
-// Samples of one layer, by the first wave of the block: abscissae xk, basis
-// h0k, and the sums A, Q, cSH (fixed butterfly order, so every kernel that
-// calls this gets the same bits).  The caller synchronises afterwards.
-__device__ __forceinline__ void layer_tables(LayerSh *sh, double *xk, double *h0k, const LayerGeom &g,
-                                             double p1s, double p2s, double d_s, double cG, double cS)
+// Basis value h0 = 10x^3 - 15x^4 + 6x^5 at x = t/T.
+__device__ __forceinline__ double basis_h0(double t, double T)
 {
-    if (threadIdx.x >= MP_WAVE) return;
+    const double tau = t / T;
+    return tau * tau * tau * (10.0 + tau * (-15.0 + 6.0 * tau));
+}
+
+// A, Q, cSH of one layer: one thread, samples in index order, so every kernel
+// that calls this gets the same bits.
+__device__ __forceinline__ LayerConst layer_const(const LayerGeom &g, double p1s, double p2s, double d_s,
+                                                  double cG, double cS)
+{
     const double T = p2s - p1s;
     double sa = 0.0, sb = 0.0, sq = 0.0;
-    for (int k = threadIdx.x; k < g.K; k += MP_WAVE) {
-        double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
-        double tau = x / T;
-        double t2 = tau * tau;
-        double h0 = t2 * tau * (10.0 + tau * (-15.0 + 6.0 * tau));
-        double w = tau - 1.0;
-        double h1 = 30.0 * t2 * w * w / T;
-        double h2 = 60.0 * tau * (1.0 + tau * (-3.0 + 2.0 * tau)) / (T * T);
-        double h3 = 60.0 * (1.0 + tau * (-6.0 + 6.0 * tau)) / (T * T * T);
-        xk[k] = x;
-        h0k[k] = h0;
+    for (int k = 0; k < g.K; ++k) {
+        const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
+        const double tau = x / T;
+        const double t2 = tau * tau;
+        const double h0 = t2 * tau * (10.0 + tau * (-15.0 + 6.0 * tau));
+        const double w = tau - 1.0;
+        const double h1 = 30.0 * t2 * w * w / T;
+        const double h2 = 60.0 * tau * (1.0 + tau * (-3.0 + 2.0 * tau)) / (T * T);
+        const double h3 = 60.0 * (1.0 + tau * (-6.0 + 6.0 * tau)) / (T * T * T);
         sa += h0;
         sb += h0 * h0;
         sq += h1 * h1 + h2 * h2 + h3 * h3;
     }
-    sa = wave_sum_f64(sa);
-    sb = wave_sum_f64(sb);
-    sq = wave_sum_f64(sq);
-    if (threadIdx.x == 0) {
-        sh->A = sa;
-        sh->cSH = cS * sq;
-        sh->Q = cG * sb + cS * sq;
-        sh->n_ent = 0;
-    }
+    LayerConst c;
+    c.A = sa;
+    c.cSH = cS * sq;
+    c.Q = cG * sb + cS * sq;
+    return c;
 }
 
 // Compacts the (sample k, obstacle o) pairs with |x_k - ob_s| < ob_dist into
-// LDS (arbitrary order; the collision test is an OR).  sh->n_ent must be 0 on
-// entry; the caller synchronises afterwards.  n_ent may exceed SL_E_CAP:
+// LDS (arbitrary order; the collision test is an OR).  One obstacle per thread;
+// only the samples around the obstacle are visited (the index window is
+// conservative, the test itself uses the exact abscissa).  *n_ent must be 0 on
+// entry; the caller synchronises afterwards.  *n_ent may exceed SL_E_CAP:
 // entries beyond the capacity are dropped and callers fall back to testing
 // every pair directly.
-__device__ __forceinline__ void build_entries(LayerSh *sh, const double *xk, const double *h0k, int K,
+__device__ __forceinline__ void build_entries(int *n_ent, const LayerGeom &g, double p1s, double p2s, double d_s,
                                               double *e_h0, double *e_ol, double *e_ds2, const double *ob_s,
-                                              const double *ob_l, int n_ob, double r2)
+                                              const double *ob_l, int n_ob, double r, double r2)
 {
+    const double T = p2s - p1s;
     for (int o = threadIdx.x; o < n_ob; o += blockDim.x) {
-        double os = ob_s[o], ol = ob_l[o];
-        for (int k = 0; k < K; ++k) {
-            double ds = xk[k] - os;
-            double ds2 = ds * ds;
+        const double os = ob_s[o], ol = ob_l[o];
+        int k_lo = 0, k_hi = g.K - 1;
+        if (g.K > 8) {
+            const double c = (os - p1s) / d_s, w = r / d_s + 2.0;
+            k_lo = (c - w > 0.0) ? (int)(c - w) : 0;
+            k_hi = (c + w < (double)(g.K - 2)) ? (int)(c + w) : g.K - 2;
+        }
+        auto test = [&](int k) {
+            const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
+            const double ds = x - os;
+            const double ds2 = ds * ds;
             if (ds2 < r2) {
-                int slot = atomicAdd(&sh->n_ent, 1);
+                const int slot = atomicAdd(n_ent, 1);
                 if (slot < SL_E_CAP) {
-                    e_h0[slot] = h0k[k];
+                    e_h0[slot] = basis_h0(x, T);
                     e_ol[slot] = ol;
                     e_ds2[slot] = ds2;
                 }
             }
-        }
+        };
+        for (int k = k_lo; k <= k_hi; ++k) test(k);
+        if (k_hi < g.K - 1) test(g.K - 1); // the appended end point sits off the grid
     }
 }
 
@@ -157,15 +157,16 @@ __device__ __forceinline__ bool pair_hit(double l1, double dl, double h0, double
 template <int NE>
 struct Collider {
     double h0[NE > 0 ? NE : 1], ol[NE > 0 ? NE : 1], ds2[NE > 0 ? NE : 1];
-    const double *e_h0, *e_ol, *e_ds2, *xk, *h0k, *ob_s, *ob_l;
-    int n_ent, K, n_ob;
-    double r2;
+    const double *e_h0, *e_ol, *e_ds2, *ob_s, *ob_l;
+    LayerGeom g;
+    double p1s, p2s, d_s, r2;
+    int n_ent, n_ob;
     __device__ __forceinline__ void init(const double *eh, const double *eo, const double *ed, int ne,
-                                         const double *xk_, const double *h0k_, int K_, const double *obs,
-                                         const double *obl, int nob, double r2_)
+                                         const LayerGeom &g_, double p1s_, double p2s_, double d_s_,
+                                         const double *obs, const double *obl, int nob, double r2_)
     {
         e_h0 = eh; e_ol = eo; e_ds2 = ed; n_ent = ne;
-        xk = xk_; h0k = h0k_; K = K_; ob_s = obs; ob_l = obl; n_ob = nob; r2 = r2_;
+        g = g_; p1s = p1s_; p2s = p2s_; d_s = d_s_; ob_s = obs; ob_l = obl; n_ob = nob; r2 = r2_;
         if constexpr (NE > 0) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
@@ -185,12 +186,14 @@ struct Collider {
         } else if constexpr (NE == -1) {
             for (int e = 0; e < n_ent; ++e) h |= pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
         } else if constexpr (NE == -2) {
-            for (int o = 0; o < n_ob; ++o) {
-                const double os = ob_s[o], olv = ob_l[o];
-                for (int k = 0; k < K; ++k) {
-                    double ds = xk[k] - os;
-                    double d2 = ds * ds;
-                    if (d2 < r2) h |= pair_hit(l1, dl, h0k[k], olv, d2, r2);
+            const double T = p2s - p1s;
+            for (int k = 0; k < g.K; ++k) {
+                const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
+                const double hk = basis_h0(x, T);
+                for (int o = 0; o < n_ob; ++o) {
+                    const double ds = x - ob_s[o];
+                    const double d2 = ds * ds;
+                    if (d2 < r2) h |= pair_hit(l1, dl, hk, ob_l[o], d2, r2);
                 }
             }
         }
@@ -220,16 +223,16 @@ struct SrcSh {
 
 // Relaxes target l2 = threadIdx.x of layer s: nearest predecessor first, then
 // outward walks that stop once cS*H*dl^2 alone exceeds the best cost so far.
+// w_inv = 1/(cS*H) with its safety factor, or 0 when the bound does not apply.
 template <int NE>
 __device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int n_src, const SrcSh &src,
-                                               const double *lcur_g, const LayerSh *sh, double m_prev,
+                                               const double *lcur_g, double Q, double w_inv, double m_prev,
                                                double g_max, bool sorted, double pen, const Collider<NE> &col,
                                                double *cost_cur, unsigned char *idx8)
 {
     const int n_l = a.in.n_l, l2 = threadIdx.x;
     if (l2 >= n_l) return MP_INF;
     const double l2v = lcur_g[l2];
-    const double Q = sh->Q, cSH = sh->cSH;
     auto eval = [&](int j, double l1, double cp, double dl) {
         const double2 gu = src.gu[j];
         double e = edge_closed_form(dl, gu.x, gu.y, Q);
@@ -241,13 +244,12 @@ __device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int
     double best = eval(j0, lc.x, lc.y, l2v - lc.x);
     int bj = j0;
     // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
-    // m_prev + cSH*dl^2 up to rounding, which the slack terms cover.  The bound
-    // needs Q/cSH to be moderate (error of the closed form relative to cSH*dl^2).
+    // m_prev + cSH*dl^2 up to rounding, which the slack terms cover
     double w2 = MP_INF;
-    if (cSH > 0.0 && Q <= 1e5 * cSH) {
+    if (w_inv > 0.0) {
         double gap = best - m_prev;
         gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
-        w2 = gap / (cSH * (1.0 - 1e-9));
+        w2 = gap * w_inv;
     }
     for (int j = j0 - 1; j >= 0; --j) {
         lc = src.lc[j];
@@ -278,9 +280,12 @@ __device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int
 }
 
 // Fused SL plan: one workgroup per scenario (one thread per lane of the lattice)
-// walks the layers; edge costs never leave the chip.  Dynamic LDS layout:
-//   cost_cur[n_lp] | lc[n_lp] double2 | gu[n_lp] double2 | xk[K_CAP] h0k[K_CAP]   (n_lp = n_l rounded up to even)
-//   e_h0[E_CAP] e_ol[E_CAP] e_ds2[E_CAP] | red_min[8] red_max[8] | LayerSh | idx8[n_s*n_l] u8
+// walks the layers; edge costs never leave the chip.  A prologue computes every
+// layer's constants in parallel (one thread per layer); the layer loop then
+// costs two barriers per layer.  Dynamic LDS layout (n_lp = n_l rounded up to even):
+//   cost_cur[n_lp] | lc[n_lp] double2 | gu[n_lp] double2 | layA layQ layW layDelta [n_s] each
+//   e_h0[E_CAP] e_ol[E_CAP] e_ds2[E_CAP] | red_min[8] red_max[8] | layK[n_s] layN[n_s] int
+//   misc[4] int | idx8[n_s*n_l] u8
 __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
@@ -292,15 +297,19 @@ __global__ void sl_plan_kernel(SlDev a)
     SrcSh src;
     src.lc = (double2 *)(cost_cur + n_lp);
     src.gu = src.lc + n_lp;
-    double *xk = (double *)(src.gu + n_lp);
-    double *h0k = xk + MP_SL_K_CAP;
-    double *e_h0 = h0k + MP_SL_K_CAP;
+    double *layA = (double *)(src.gu + n_lp);
+    double *layQ = layA + n_s;
+    double *layW = layQ + n_s;
+    double *layDelta = layW + n_s;
+    double *e_h0 = layDelta + n_s;
     double *e_ol = e_h0 + SL_E_CAP;
     double *e_ds2 = e_ol + SL_E_CAP;
     double *red_min = e_ds2 + SL_E_CAP;
     double *red_max = red_min + 8;
-    LayerSh *sh = (LayerSh *)(red_max + 8);
-    unsigned char *idx8 = (unsigned char *)(sh + 1);
+    int *layK = (int *)(red_max + 8);
+    int *layN = layK + n_s;
+    int *misc = layN + n_s; // [0] pair count, ping-ponged over [0]/[1]
+    unsigned char *idx8 = (unsigned char *)(misc + 4);
 
     const double *s_layers = a.in.s_layers + (size_t)b * n_s;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
@@ -314,47 +323,80 @@ __global__ void sl_plan_kernel(SlDev a)
     const int mid_l = a.p.mid_l;
     const double ego_s = a.in.ego_sl[2 * b], ego_l = a.in.ego_sl[2 * b + 1];
 
+    // ---- prologue: per-layer constants, one thread per layer ----------------
+    double u_loc = 0.0; // largest |l - mid| over the lattice (bounds every straight-edge cost)
+    for (int s = tid; s < n_s; s += nt) {
+        const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
+        const double p2s = s_layers[s];
+        const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
+        layK[s] = g.K;
+        layN[s] = g.n;
+        layDelta[s] = g.delta;
+        if (g.K >= 0) {
+            const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
+            layA[s] = c.A;
+            layQ[s] = c.Q;
+            // the pruning bound needs Q/cSH moderate (rounding of the closed form
+            // relative to cSH*dl^2); 0 switches it off for the layer
+            layW[s] = (c.cSH > 0.0 && c.Q <= 1e5 * c.cSH) ? (1.0 + 1e-9) / (c.cSH * (1.0 - 1e-9)) : 0.0;
+        }
+    }
+    {
+        const int rows = a.in.l_rstride ? n_s : 1;
+        for (int i = tid; i < rows * n_l; i += nt) {
+            const int row = i / n_l;
+            const double *lr = lbase + (size_t)row * a.in.l_rstride;
+            const double u = fabs(lr[i - row * n_l] - lr[mid_l]);
+            u_loc = u > u_loc ? u : u_loc;
+        }
+        u_loc = fabs(ego_l - lbase[(size_t)(n_s - 1) * a.in.l_rstride + mid_l]) > u_loc
+                    ? fabs(ego_l - lbase[(size_t)(n_s - 1) * a.in.l_rstride + mid_l]) : u_loc;
+        u_loc = -wave_min_f64(-u_loc);
+        if ((tid & (MP_WAVE - 1)) == 0) red_max[wave] = u_loc;
+        if (tid == 0) misc[0] = misc[1] = 0;
+    }
+    __syncthreads();
+    double u_max = red_max[0];
+    for (int w = 1; w < nw; ++w) u_max = red_max[w] > u_max ? red_max[w] : u_max;
+    const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
+
     int status = MP_SL_FOUND;
     int done = 0;
     double m_prev = 0.0; // minimum accumulated cost over the previous layer
     for (int s = 0; s < n_s; ++s) {
+        LayerGeom geo;
+        geo.K = layK[s];
+        geo.n = layN[s];
+        geo.delta = layDelta[s];
+        if (geo.K < 0) { status = geo.K; break; }
         const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
         const double p2s = s_layers[s];
         const int n_src = (s == 0) ? 1 : n_l;
         const double *lprev_g = lbase + (size_t)(s == 0 ? n_s - 1 : s - 1) * a.in.l_rstride;
         const double *lcur_g = lbase + (size_t)s * a.in.l_rstride;
         const double mid = lprev_g[mid_l];
-        const LayerGeom geo = layer_geom(p1s, p2s, d_s, n_ob);
-        if (geo.bad) { status = geo.bad; break; }
-        layer_tables(sh, xk, h0k, geo, p1s, p2s, d_s, cG, cS);
-        __syncthreads();
+        const double A = layA[s], Q = layQ[s], w_inv = layW[s];
+        int *n_ent_sh = misc + (s & 1);
         // source-side arrays (cost_cur still holds the previous layer's row),
-        // sortedness of the source row, largest straight-edge cost, pair list
-        const double A = sh->A;
+        // sortedness of the source row, pair list
         int sorted_loc = 1;
-        double g_loc = 0.0;
         for (int j = tid; j < n_src; j += nt) {
             const double l1 = (s == 0) ? ego_l : lprev_g[j];
             const double u = l1 - mid;
-            const double g = guide_straight(u, geo.K, w_d, d_s);
             src.lc[j] = make_double2(l1, (s == 0) ? 0.0 : cost_cur[j]);
-            src.gu[j] = make_double2(g, 2.0 * cG * A * u);
-            g_loc = g > g_loc ? g : g_loc;
+            src.gu[j] = make_double2(guide_straight(u, geo.K, w_d, d_s), 2.0 * cG * A * u);
             if (s > 0 && j > 0 && !(lprev_g[j - 1] <= l1)) sorted_loc = 0;
         }
-        g_loc = -wave_min_f64(-g_loc);
-        if ((tid & (MP_WAVE - 1)) == 0) red_max[wave] = g_loc;
-        build_entries(sh, xk, h0k, geo.K, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r2);
+        build_entries(n_ent_sh, geo, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r, r2);
         const bool sorted = __syncthreads_and(sorted_loc) != 0;
-        double g_max = red_max[0];
-        for (int w = 1; w < nw; ++w) g_max = red_max[w] > g_max ? red_max[w] : g_max;
-        const int n_ent = sh->n_ent;
+        const int n_ent = *n_ent_sh;
+        if (tid == 0) misc[(s + 1) & 1] = 0; // next layer's counter
         double best;
 #define SL_RELAX(NE)                                                                                     \
     {                                                                                                    \
         Collider<NE> col;                                                                                \
-        col.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);                        \
-        best = relax_target<NE>(a, b, s, n_src, src, lcur_g, sh, m_prev, g_max, sorted, pen, col,        \
+        col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);                    \
+        best = relax_target<NE>(a, b, s, n_src, src, lcur_g, Q, w_inv, m_prev, g_max, sorted, pen, col,  \
                                 cost_cur, idx8);                                                         \
     }
         switch (n_ent) {
@@ -426,9 +468,9 @@ __global__ void sl_plan_kernel(SlDev a)
 // doubles.  Same arithmetic as the fused kernel, bit for bit.
 __global__ void sl_edge_cost_kernel(SlDev a)
 {
-    __shared__ double xk[MP_SL_K_CAP], h0k[MP_SL_K_CAP];
     __shared__ double e_h0[SL_E_CAP], e_ol[SL_E_CAP], e_ds2[SL_E_CAP];
-    __shared__ LayerSh sh;
+    __shared__ LayerConst lay;
+    __shared__ int n_ent_sh;
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int n_l = a.in.n_l, n_s = a.in.n_s;
     const double *s_layers = a.in.s_layers + (size_t)b * n_s;
@@ -448,21 +490,24 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     const double mid = lprev_g[a.p.mid_l];
     double *out = a.edge_cost + ((size_t)b * n_s + s) * n_l * n_l;
     const LayerGeom geo = layer_geom(p1s, p2s, d_s, n_ob);
-    if (geo.bad) {
-        if (tid == 0) atomicMin(&a.status[b], geo.bad);
+    if (geo.K < 0) {
+        if (tid == 0) atomicMin(&a.status[b], geo.K);
         for (int e = tid; e < n_l * n_l; e += nt) out[e] = __builtin_nan("");
         return;
     }
-    layer_tables(&sh, xk, h0k, geo, p1s, p2s, d_s, cG, cS);
+    if (tid == 0) {
+        lay = layer_const(geo, p1s, p2s, d_s, cG, cS);
+        n_ent_sh = 0;
+    }
     __syncthreads();
-    const double A = sh.A, Q = sh.Q;
-    build_entries(&sh, xk, h0k, geo.K, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r2);
+    const double A = lay.A, Q = lay.Q;
+    build_entries(&n_ent_sh, geo, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r, r2);
     __syncthreads();
-    const int n_ent = sh.n_ent;
+    const int n_ent = n_ent_sh;
     Collider<-1> col_list;
     Collider<-2> col_all;
-    col_list.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);
-    col_all.init(e_h0, e_ol, e_ds2, n_ent, xk, h0k, geo.K, ob_s, ob_l, n_ob, r2);
+    col_list.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+    col_all.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
     for (int e = tid; e < n_l * n_l; e += nt) {
         const int l2 = e / n_l, j = e - l2 * n_l;
         if (j >= n_src) { out[e] = __builtin_nan(""); continue; }
@@ -587,8 +632,8 @@ extern void mp_set_error(const char *fmt, ...);
 
 static size_t sl_plan_lds_bytes(int n_s, int n_l)
 {
-    size_t d = (size_t)5 * ((n_l + 1) & ~1) + 2 * MP_SL_K_CAP + 3 * SL_E_CAP + 16;
-    size_t bytes = d * sizeof(double) + sizeof(LayerSh);
+    size_t d = (size_t)5 * ((n_l + 1) & ~1) + 4 * (size_t)n_s + 3 * SL_E_CAP + 16;
+    size_t bytes = d * sizeof(double) + (2 * (size_t)n_s + 4) * sizeof(int);
     bytes += (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
