@@ -116,7 +116,7 @@ int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const double *edge_cost,
  * (Planning/DP_Speed/speed_planner.py:57-162).  Scenario b uses an
  * n_t x n_s[b] grid (n_s[b] <= n_s_max) with cell size ds x dt; blocked
  * intervals of time layer i are s_down/s_up[b][i][0..n_reg[b][i]).
- * Limits: n_t <= 64, n_s_max <= 1024, r_max <= 64.
+ * Limits: n_t <= 64, n_s_max <= 1024, r_max <= 256.
  * Outputs (cost, pre may be NULL):
  *   cost [B][n_t][n_s_max], pre [B][n_t][n_s_max]   row 0 = 0 / -1 (st_map.py:86-91)
  *   path_s_ind [B][n_t]  backtracked s indices, -1 padded; path_len [B] = end_i+1 */
@@ -146,12 +146,39 @@ int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const double *pa
  * knots_x/knots_y [B][n_knots_max], first n_knots[b] used; vec [B] end slope;
  * ego_xy [B][2] point whose projection fixes the Frenet origin; d_x = 0.5.
  * Outputs, each [B][m_max] with M[b] valid: tab_x, tab_y, tab_s, tab_theta,
- * tab_kappa; origin [B][2] = (rx_ori, ry_ori); status [B] MP_RL_*. */
+ * tab_kappa; origin [B][4] = (rx_ori, ry_ori, get_s(last knot) -- the length
+ * SLMap lays its layers along, sl_map.py:52 --, rx_max); status [B] MP_RL_*.
+ * Optional (all five NULL to skip) Frenet->Cartesian table of get_rxy
+ * (cfc.py:72-86): abscissae get_arange(rx_ori, rx_max, d_x) with their arc
+ * length, ordinate and heading, inv_* [B][m_max], n_inv [B]. */
 int mp_refline_tables(int32_t B, const double *knots_x, const double *knots_y,
                       const int32_t *n_knots, int32_t n_knots_max, const double *vec,
                       const double *ego_xy, double d_x, int32_t m_max, double *tab_x,
                       double *tab_y, double *tab_s, double *tab_theta, double *tab_kappa,
-                      int32_t *M, double *origin, int32_t *status, void *stream);
+                      int32_t *M, double *origin, int32_t *status, double *inv_x, double *inv_s,
+                      double *inv_y, double *inv_theta, int32_t *n_inv, void *stream);
+
+/* Replaces CartesianFrenetConverter.frenet_to_cartesian + get_rxy
+ * (Model/cartesian_frenet_conversion.py:55-60, 72-86) for n_pts points:
+ * the first table abscissa whose arc length reaches s (the line's end if none
+ * does), offset by l along the normal. */
+int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, const int32_t *pt_scn,
+                 int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
+                 const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream);
+
+/* Replaces Curve.__init__ + Curve.calc_point_arr (Model/curve.py:13-73) for the
+ * planner's output splines, one curve per scenario: knots_t/knots_x
+ * [B][n_knots_max] (first n_knots[b] used), end slope vec [B], spacing dt.
+ *   mode 0: samples get_arange(t0, t0+sum(T), dt)  -- SLMap.path_sampling (sl_map.py:114-126)
+ *   mode 1: samples get_arange(t0, t_last, dt)     -- SpeedPlanner.plan (speed_planner.py:44-49)
+ *   mode 2: samples query [B][q_max], n_query [B]  -- path_sampling(curve, False, ss)
+ * Outputs [B][q_max]: out_t (abscissae), out_x (value), out_dx (first
+ * derivative, may be NULL); n_out [B]; status [B] MP_RL_* (MP_RL_E_INDEX where
+ * the reference raises IndexError). */
+int mp_curve_eval(int32_t B, const double *knots_t, const double *knots_x, const int32_t *n_knots,
+                  int32_t n_knots_max, const double *vec, double dt, int32_t mode,
+                  const double *query, const int32_t *n_query, int32_t q_max, double *out_t,
+                  double *out_x, double *out_dx, int32_t *n_out, int32_t *status, void *stream);
 
 /* Replaces CartesianFrenetConverter.cartesian_to_frenet
  * (Model/cartesian_frenet_conversion.py:32-53) + Curve.projection

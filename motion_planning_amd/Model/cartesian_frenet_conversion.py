@@ -3,11 +3,9 @@
 Interface of the reference's Model/cartesian_frenet_conversion.py.  The
 constructor and cartesian_to_frenet run on the GPU (reference-line tables +
 nearest-sample projection, batch.refline_tables / batch.c2f); one converter is
-a batch of one scenario, and cartesian_to_frenet_batch converts many points in
-one launch.  The inverse direction walks the host-side spline.
+a batch of one scenario; cartesian_to_frenet_batch / frenet_to_cartesian_batch
+convert many points in one launch.
 """
-import math
-
 import numpy as np
 
 from .. import _lib, batch as mb
@@ -69,7 +67,15 @@ class CartesianFrenetConverter:
             print("Error, cannot get rxy")
         return rx, self.ref_curve.calc_point(rx, 0)
 
+    def frenet_to_cartesian_batch(self, ss, ls):
+        """Vector form of frenet_to_cartesian: one GPU launch over the
+        Frenet->Cartesian table built with the converter."""
+        ss = np.atleast_1d(np.asarray(ss, dtype=np.float64))
+        x, y = mb.f2c(self.tables, ss, ls, np.zeros(len(ss), np.int32))
+        return x.cpu().numpy(), y.cpu().numpy()
+
     def frenet_to_cartesian(self, s, l):
-        rx, ry = self.get_rxy(s)
-        rtheta = np.arctan(self.ref_curve.calc_point(rx, 1))
-        return rx - l * math.sin(rtheta), ry + l * math.cos(rtheta)
+        """(x, y) of Frenet point (s, l): the first 0.5 m abscissa whose arc length
+        reaches s, offset by l along the normal there (cfc.py:55-60)."""
+        x, y = self.frenet_to_cartesian_batch([s], [l])
+        return float(x[0]), float(y[0])

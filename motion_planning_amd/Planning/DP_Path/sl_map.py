@@ -95,4 +95,8 @@ class SLMap:
 
     def path_convert(self, point_list):
         """Frenet -> robot frame (sl_map.py:129-134)."""
-        return [to_point(*self.converter.frenet_to_cartesian(p[0], p[1])) for p in point_list]
+        if len(point_list) == 0:
+            return []
+        pts = np.asarray(point_list, dtype=np.float64).reshape(-1, 2)
+        xs, ys = self.converter.frenet_to_cartesian_batch(pts[:, 0], pts[:, 1])
+        return [to_point(x, y) for x, y in zip(xs, ys)]

@@ -41,7 +41,10 @@ SIGNATURES = {
     "mp_st_regions": (C.c_int, [C.c_int32] * 2 + [_vp] * 3 + [C.c_int32] + [_vp] * 4 + [C.c_int32] + [_vp] * 4
                       + [C.c_int32] * 2 + [_vp] * 5),
     "mp_refline_tables": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_double, C.c_int32]
-                          + [_vp] * 9),
+                          + [_vp] * 14),
+    "mp_f2c_batch": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32] + [_vp] * 8),
+    "mp_curve_eval": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int32, _vp, _vp,
+                                C.c_int32] + [_vp] * 6),
     "mp_c2f_batch": (C.c_int, [C.c_int32] + [_vp] * 5 + [C.c_int32] + [_vp] * 10),
 }
 

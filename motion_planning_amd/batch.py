@@ -200,13 +200,20 @@ class RefLineTables:
         self.tab_theta = torch.zeros((B, m_max), **f)
         self.tab_kappa = torch.zeros((B, m_max), **f)
         self.M = torch.zeros(B, dtype=torch.int32, device=device)
-        self.origin = torch.zeros((B, 2), **f)
+        self.origin = torch.zeros((B, 4), **f)   # rx_ori, ry_ori, get_s(last knot), rx_max
         self.status = torch.zeros(B, dtype=torch.int32, device=device)
+        # Frenet -> Cartesian table (abscissa, arc length, ordinate, heading)
+        self.inv_x = torch.zeros((B, m_max), **f)
+        self.inv_s = torch.zeros((B, m_max), **f)
+        self.inv_y = torch.zeros((B, m_max), **f)
+        self.inv_theta = torch.zeros((B, m_max), **f)
+        self.n_inv = torch.zeros(B, dtype=torch.int32, device=device)
 
 
 def refline_tables(knots_x, knots_y, n_knots, vec, ego_xy, d_x=0.5, m_max=None):
     """Reference-line tables (replaces CartesianFrenetConverter.__init__ and the
-    per-sample parts of cartesian_to_frenet, cartesian_frenet_conversion.py:11-70).
+    per-sample parts of cartesian_to_frenet / frenet_to_cartesian,
+    cartesian_frenet_conversion.py:11-86).
 
     knots_x / knots_y [B, n_knots_max]; n_knots [B]; vec [B]; ego_xy [B, 2]."""
     knots_x, knots_y = to_dev(knots_x), to_dev(knots_y)
@@ -219,7 +226,8 @@ def refline_tables(knots_x, knots_y, n_knots, vec, ego_xy, d_x=0.5, m_max=None):
     t = RefLineTables(B, m_max, knots_x.device)
     check(lib().mp_refline_tables(B, _p(knots_x), _p(knots_y), _p(n_knots), n_knots_max, _p(vec), _p(ego_xy),
                                   float(d_x), m_max, _p(t.tab_x), _p(t.tab_y), _p(t.tab_s), _p(t.tab_theta),
-                                  _p(t.tab_kappa), _p(t.M), _p(t.origin), _p(t.status), _stream()),
+                                  _p(t.tab_kappa), _p(t.M), _p(t.origin), _p(t.status), _p(t.inv_x), _p(t.inv_s),
+                                  _p(t.inv_y), _p(t.inv_theta), _p(t.n_inv), _stream()),
           "mp_refline_tables")
     return t
 
@@ -243,3 +251,44 @@ def c2f(tables, px, py, pt_scn, vx=None, vy=None):
                              _p(tables.tab_theta), _p(tables.tab_kappa), _p(tables.M), _p(s), _p(l), _p(s_dt),
                              _stream()), "mp_c2f_batch")
     return (s, l, s_dt) if order1 else (s, l)
+
+
+def f2c(tables, s, l, pt_scn):
+    """Batched frenet_to_cartesian (cartesian_frenet_conversion.py:55-60, 72-86)."""
+    s, l = to_dev(s).reshape(-1), to_dev(l).reshape(-1)
+    pt_scn = to_dev(pt_scn, torch.int32).reshape(-1)
+    n = s.numel()
+    x = torch.empty(n, dtype=torch.float64, device=s.device)
+    y = torch.empty_like(x)
+    check(lib().mp_f2c_batch(n, _p(s), _p(l), _p(pt_scn), tables.m_max, _p(tables.inv_x), _p(tables.inv_s),
+                             _p(tables.inv_y), _p(tables.inv_theta), _p(tables.n_inv), _p(x), _p(y), _stream()),
+          "mp_f2c_batch")
+    return x, y
+
+
+CURVE_ARC, CURVE_KNOTS, CURVE_QUERY = 0, 1, 2
+
+
+def curve_eval(knots_t, knots_x, n_knots, vec, dt, mode, q_max, query=None, n_query=None, want_dx=False):
+    """Batched spline build + sampling (Curve.__init__ + calc_point_arr, curve.py:13-73).
+
+    mode CURVE_ARC: samples every dt over [t0, t0 + sum(T)] (SLMap.path_sampling);
+    CURVE_KNOTS: over [t0, last knot] (SpeedPlanner.plan); CURVE_QUERY: at query
+    [B, q_max] (first n_query[b]).  Returns dict(t, x[, dx], n, status)."""
+    knots_t, knots_x = to_dev(knots_t), to_dev(knots_x)
+    B, nk = knots_t.shape
+    n_knots, vec = to_dev(n_knots, torch.int32), to_dev(vec)
+    dev = knots_t.device
+    if mode == CURVE_QUERY:
+        query = to_dev(query).reshape(B, -1)
+        assert query.shape[1] == q_max
+        n_query = to_dev(n_query, torch.int32)
+    out_t = torch.zeros((B, q_max), dtype=torch.float64, device=dev)
+    out_x = torch.zeros_like(out_t)
+    out_dx = torch.zeros_like(out_t) if want_dx else None
+    n_out = torch.empty(B, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib().mp_curve_eval(B, _p(knots_t), _p(knots_x), _p(n_knots), nk, _p(vec), float(dt), int(mode),
+                              _p(query), _p(n_query), q_max, _p(out_t), _p(out_x), _p(out_dx), _p(n_out),
+                              _p(status), _stream()), "mp_curve_eval")
+    return dict(t=out_t, x=out_x, dx=out_dx, n=n_out, status=status)

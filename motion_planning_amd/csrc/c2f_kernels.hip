@@ -110,7 +110,28 @@ struct RlDev {
     int32_t *M;
     double *origin;
     int32_t *status;
+    double *inv_x, *inv_s, *inv_y, *inv_theta; // Frenet->Cartesian table, optional
+    int32_t *n_inv;
 };
+
+// Curve.calc_arc_len(rx_ori, x) (curve.py:93-115) with the pieces every call
+// shares precomputed: the origin's segment (st_i, st_t) to its end and every
+// full segment.
+__device__ double arc_from_origin(const double *T, int n, const double *coef, const double *seg_full,
+                                  double first_piece, int st_i, double st_t, double t0, double t1, double dt,
+                                  int *bad)
+{
+    if (t0 > t1) return 0.0;
+    int en_i;
+    double en_t;
+    curve_get_i(T, n, t1, &en_i, &en_t);
+    if (en_t > T[en_i]) en_t = T[en_i];
+    if (st_i == en_i) return quintic_arc_len(coef + 6 * st_i, st_t, en_t, dt, bad);
+    double arc = first_piece;
+    for (int i = st_i + 1; i < en_i; ++i) arc += seg_full[i];
+    arc += quintic_arc_len(coef + 6 * en_i, 0, en_t, dt, bad);
+    return arc;
+}
 
 // One workgroup per scenario.  Dynamic LDS: tsum[m_max] (double) seg[m_max] (int).
 __global__ void refline_tables_kernel(RlDev a)
@@ -120,7 +141,7 @@ __global__ void refline_tables_kernel(RlDev a)
     __shared__ double vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
     __shared__ double red_c[16];
     __shared__ int red_i[16];
-    __shared__ double sc_d[8]; // t_max, delta, first piece, t_bios, st_t
+    __shared__ double sc_d[8]; // t_max, delta, first piece, s_end
     __shared__ int sc_i[8];    // M, n, status, k_ori, st_i
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     double *tsum = smem;
@@ -236,29 +257,41 @@ __global__ void refline_tables_kernel(RlDev a)
     const double first_piece = sc_d[2];
     for (int k = tid; k < M; k += nt) {
         const double x = arange_value(k, na, 0.0, t_max, dt, delta) + t_bios;
-        const double t1 = x - t_bios;
-        double arc;
-        if (t0 > t1) arc = 0.0;
-        else {
-            int en_i;
-            double en_t;
-            curve_get_i(T, n, t1, &en_i, &en_t);
-            if (en_t > T[en_i]) en_t = T[en_i];
-            if (st_i == en_i) arc = quintic_arc_len(coef + 6 * st_i, st_t, en_t, dt, &bad);
-            else {
-                arc = first_piece;
-                for (int i = st_i + 1; i < en_i; ++i) arc += seg_full[i];
-                arc += quintic_arc_len(coef + 6 * en_i, 0, en_t, dt, &bad);
-            }
+        tab_s[k] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, x - t_bios, dt, &bad);
+    }
+    // get_s of the last knot: the length SLMap lays its layers along (sl_map.py:52)
+    const double rx_max = kx[n];
+    if (tid == 0)
+        sc_d[3] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, rx_max - t_bios, dt, &bad);
+    // Frenet->Cartesian table (cfc.py:55-60, 72-86): abscissae
+    // get_arange(rx_ori, rx_max, d_x) with their arc length, ordinate and heading
+    int n_inv = 0;
+    if (a.inv_x) {
+        int ng;
+        double dg;
+        n_inv = arange_count(rx_ori, rx_max, dt, a.m_max, &ng, &dg);
+        if (n_inv < 0) { bad = 1; n_inv = 0; }
+        for (int k = tid; k < n_inv; k += nt) {
+            const double x = arange_value(k, ng, rx_ori, rx_max, dt, dg);
+            int ii;
+            double tt;
+            curve_get_i(T, n, x - t_bios, &ii, &tt);
+            const size_t o = (size_t)b * a.m_max + k;
+            a.inv_x[o] = x;
+            a.inv_s[o] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, x - t_bios, dt, &bad);
+            a.inv_y[o] = quintic_eval(coef + 6 * ii, tt, 0);
+            a.inv_theta[o] = atan(quintic_eval(coef + 6 * ii, tt, 1));
         }
-        tab_s[k] = arc;
     }
     bad = __syncthreads_or(bad);
     if (tid == 0) {
         a.status[b] = bad ? MP_RL_E_CAPACITY : MP_RL_OK;
         a.M[b] = bad ? 0 : M;
-        a.origin[2 * b] = rx_ori;
-        a.origin[2 * b + 1] = tab_y[k_ori];
+        a.origin[4 * b] = rx_ori;
+        a.origin[4 * b + 1] = tab_y[k_ori];
+        a.origin[4 * b + 2] = sc_d[3];
+        a.origin[4 * b + 3] = rx_max;
+        if (a.n_inv) a.n_inv[b] = bad ? 0 : n_inv;
     }
 }
 
@@ -311,6 +344,137 @@ __global__ void c2f_kernel(C2fDev a)
     }
 }
 
+struct F2cDev {
+    int32_t n_pts, m_max;
+    const double *s, *l;
+    const int32_t *pt_scn;
+    const double *inv_x, *inv_s, *inv_y, *inv_theta, *origin;
+    const int32_t *n_inv;
+    double *x, *y;
+};
+
+// One thread per point (cartesian_frenet_conversion.py:55-60 with get_rxy
+// :72-86): the first table abscissa whose arc length reaches s; past the table
+// the end of the line, whose ordinate/heading sit in the last slot +1.
+__global__ void f2c_kernel(F2cDev a)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pts) return;
+    const int b = a.pt_scn[p];
+    const int n = a.n_inv[b];
+    const double s = a.s[p], l = a.l[p];
+    const double *arc = a.inv_s + (size_t)b * a.m_max;
+    int k = n - 1; // the table ends on rx_max (get_arange appends it)
+    for (int i = 0; i < n; ++i)
+        if (s <= arc[i]) { k = i; break; }
+    if (n <= 0) {
+        a.x[p] = a.y[p] = __builtin_nan("");
+        return;
+    }
+    const size_t o = (size_t)b * a.m_max + k;
+    const double th = a.inv_theta[o];
+    a.x[p] = a.inv_x[o] - l * sin(th);
+    a.y[p] = a.inv_y[o] + l * cos(th);
+}
+
+struct CvDev {
+    int32_t n_knots_max, q_max, mode;
+    const double *knots_t, *knots_x;
+    const int32_t *n_knots;
+    const double *vec;
+    double dt;
+    const double *query;
+    const int32_t *n_query;
+    double *out_t, *out_x, *out_dx;
+    int32_t *n_out, *status;
+};
+
+// Spline through knots + evaluation on an increasing sample set with
+// Curve.calc_point_arr's rules (curve.py:13-73).  One workgroup per curve.
+//   mode 0: samples get_arange(t0, t0 + np.sum(T), dt)   (SLMap.path_sampling, sl_map.py:115-118)
+//   mode 1: samples get_arange(t0, t_last, dt)           (SpeedPlanner.plan, speed_planner.py:47)
+//   mode 2: samples given by the caller                  (path_sampling(curve, False, ss))
+// Dynamic LDS: tq[q_max] tsum[q_max] (double) seg[q_max] (int).
+__global__ void curve_eval_kernel(CvDev a)
+{
+    extern __shared__ double smem[];
+    __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
+    __shared__ int sc_i[4]; // n samples, status
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    double *tq = smem, *tsum = smem + a.q_max;
+    int *seg = (int *)(smem + 2 * (size_t)a.q_max);
+    const int npts = a.n_knots[b], n = npts - 1;
+    const double *kt = a.knots_t + (size_t)b * a.n_knots_max;
+    const double *kx = a.knots_x + (size_t)b * a.n_knots_max;
+    if (n < 1 || n > RL_SEG_CAP || npts > a.n_knots_max) {
+        if (tid == 0) { a.status[b] = n < 1 ? MP_RL_E_INDEX : MP_RL_E_CAPACITY; a.n_out[b] = 0; }
+        return;
+    }
+    const double t_bios = kt[0], dt = a.dt;
+    for (int i = tid; i < n; i += nt) T[i] = kt[i + 1] - kt[i];
+    __syncthreads();
+    for (int i = tid; i <= n; i += nt)
+        vv[i] = (i == 0 || i == n) ? a.vec[b] : 1.0 * (kx[i + 1] - kx[i - 1]) / (T[i] + T[i - 1]);
+    __syncthreads();
+    for (int i = tid; i <= n; i += nt)
+        aa[i] = (i == 0 || i == n) ? 0.0 : 1.0 * (vv[i + 1] - vv[i - 1]) / (T[i] + T[i - 1]);
+    __syncthreads();
+    for (int i = tid; i < n; i += nt)
+        quintic_coef(kx[i], vv[i], aa[i], kx[i + 1], vv[i + 1], aa[i + 1], T[i], coef + 6 * i);
+    __syncthreads();
+    if (tid == 0) {
+        int st = MP_RL_OK, m = 0;
+        if (a.mode == 2) {
+            m = a.n_query[b];
+            if (m > a.q_max) { st = MP_RL_E_CAPACITY; m = 0; }
+            for (int j = 0; j < m; ++j) tq[j] = a.query[(size_t)b * a.q_max + j];
+        } else {
+            const double t_en = (a.mode == 0) ? t_bios + np_sum_gen(n, [&](int i) { return T[i]; }) : kt[n];
+            int na;
+            double delta;
+            m = arange_count(t_bios, t_en, dt, a.q_max, &na, &delta);
+            if (m < 0) { st = MP_RL_E_CAPACITY; m = 0; }
+            for (int j = 0; j < m; ++j) tq[j] = arange_value(j, na, t_bios, t_en, dt, delta);
+        }
+        if (st == MP_RL_OK && m == 0) st = MP_RL_E_INDEX; // t_arr[0] of an empty array
+        if (m > 0) {
+            const double first = tq[0] - t_bios;
+            if (first < 0.0) { st = MP_RL_E_INDEX; m = 0; }
+            else {
+                int i;
+                double tt;
+                curve_get_i(T, n, first, &i, &tt);
+                double t_sum = np_sum_gen(i + 1, [&](int q) { return T[q]; });
+                for (int j = 0; j < m; ++j) {
+                    if (tq[j] - t_bios > t_sum + dt) {
+                        i += 1;
+                        if (i < n) t_sum += T[i];
+                        else { st = MP_RL_E_INDEX; m = 0; break; }
+                    }
+                    seg[j] = i;
+                    tsum[j] = t_sum;
+                }
+            }
+        }
+        sc_i[0] = m;
+        sc_i[1] = st;
+    }
+    __syncthreads();
+    const int m = sc_i[0];
+    for (int j = tid; j < m; j += nt) {
+        const int i = seg[j];
+        const double tl = (tq[j] - t_bios) - tsum[j] + T[i];
+        const size_t o = (size_t)b * a.q_max + j;
+        a.out_t[o] = tq[j];
+        a.out_x[o] = quintic_eval(coef + 6 * i, tl, 0);
+        if (a.out_dx) a.out_dx[o] = quintic_eval(coef + 6 * i, tl, 1);
+    }
+    if (tid == 0) {
+        a.n_out[b] = m;
+        a.status[b] = sc_i[1];
+    }
+}
+
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
@@ -328,7 +492,8 @@ extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double 
                                  const int32_t *n_knots, int32_t n_knots_max, const double *vec,
                                  const double *ego_xy, double d_x, int32_t m_max, double *tab_x, double *tab_y,
                                  double *tab_s, double *tab_theta, double *tab_kappa, int32_t *M, double *origin,
-                                 int32_t *status, void *stream)
+                                 int32_t *status, double *inv_x, double *inv_s, double *inv_y,
+                                 double *inv_theta, int32_t *n_inv, void *stream)
 {
     if (B <= 0 || n_knots_max < 2 || m_max <= 0 || !(d_x > 0)) { mp_set_error("bad sizes"); return MP_E_BADARG; }
     if (!knots_x || !knots_y || !n_knots || !vec || !ego_xy || !tab_x || !tab_y || !tab_s || !tab_theta ||
@@ -336,13 +501,54 @@ extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double 
         mp_set_error("null array");
         return MP_E_BADARG;
     }
+    if (inv_x && (!inv_s || !inv_y || !inv_theta || !n_inv)) {
+        mp_set_error("the Frenet->Cartesian table needs all five arrays");
+        return MP_E_BADARG;
+    }
     if (m_max > 4096) { mp_set_error("mp_refline_tables: m_max > 4096"); return MP_E_UNSUPPORTED; }
     RlDev a{n_knots_max, m_max, knots_x, knots_y, n_knots, vec, ego_xy, d_x, tab_x, tab_y, tab_s, tab_theta,
-            tab_kappa, M, origin, status};
+            tab_kappa, M, origin, status, inv_x, inv_s, inv_y, inv_theta, n_inv};
     size_t lds = (size_t)m_max * (sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
     hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(m_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_refline_tables");
+}
+
+extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, const int32_t *pt_scn,
+                            int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
+                            const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream)
+{
+    if (n_pts <= 0 || m_max <= 0) { mp_set_error("bad sizes"); return MP_E_BADARG; }
+    if (!s || !l || !pt_scn || !inv_x || !inv_s || !inv_y || !inv_theta || !n_inv || !x || !y) {
+        mp_set_error("null array");
+        return MP_E_BADARG;
+    }
+    F2cDev a{n_pts, m_max, s, l, pt_scn, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv, x, y};
+    hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_f2c_batch");
+}
+
+extern "C" int mp_curve_eval(int32_t B, const double *knots_t, const double *knots_x, const int32_t *n_knots,
+                             int32_t n_knots_max, const double *vec, double dt, int32_t mode,
+                             const double *query, const int32_t *n_query, int32_t q_max, double *out_t,
+                             double *out_x, double *out_dx, int32_t *n_out, int32_t *status, void *stream)
+{
+    if (B <= 0 || n_knots_max < 2 || q_max <= 0 || !(dt > 0) || mode < 0 || mode > 2) {
+        mp_set_error("bad sizes/mode");
+        return MP_E_BADARG;
+    }
+    if (!knots_t || !knots_x || !n_knots || !vec || !out_t || !out_x || !n_out || !status ||
+        (mode == 2 && (!query || !n_query))) {
+        mp_set_error("null array");
+        return MP_E_BADARG;
+    }
+    if (q_max > 4096) { mp_set_error("mp_curve_eval: q_max > 4096"); return MP_E_UNSUPPORTED; }
+    CvDev a{n_knots_max, q_max, mode, knots_t, knots_x, n_knots, vec, dt, query, n_query, out_t, out_x, out_dx,
+            n_out, status};
+    size_t lds = (size_t)q_max * (2 * sizeof(double) + sizeof(int));
+    lds = (lds + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(curve_eval_kernel, dim3(B), dim3(q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_curve_eval");
 }
 
 extern "C" int mp_c2f_batch(int32_t n_pts, const double *px, const double *py, const double *vx,

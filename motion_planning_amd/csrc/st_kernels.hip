@@ -451,8 +451,8 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         return MP_E_BADARG;
     }
     if (!(ds > 0) || !(dt > 0) || !(speed_lim > 0)) { mp_set_error("ds, dt, speed_lim must be positive"); return MP_E_BADARG; }
-    if (n_t > 64 || n_s_max > 1024 || r_max > 64) {
-        mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 64");
+    if (n_t > 64 || n_s_max > 1024 || r_max > 256) {
+        mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 256");
         return MP_E_UNSUPPORTED;
     }
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,

@@ -50,7 +50,10 @@ def test_refline_tables_golden():
         close(t.tab_s[i, :M].cpu().numpy(), g[p + "tab_S"])
         close(t.tab_theta[i, :M].cpu().numpy(), g[p + "tab_th"])
         close(t.tab_kappa[i, :M].cpu().numpy(), g[p + "tab_kr"])
-        close(t.origin[i].cpu().numpy(), g[p + "ori"][:2])
+        close(t.origin[i, :2].cpu().numpy(), g[p + "ori"][:2])
+        assert float(t.origin[i, 3]) == g[p + "ori"][2]
+        # get_s of the last knot: the arc length of the last sample (it sits on the last knot)
+        close(float(t.origin[i, 2]), g[p + "tab_S"][-1])
 
 
 def test_c2f_golden():
@@ -101,7 +104,8 @@ def test_c2f_random_vs_oracle(oracle):
     s, l, sd = s.cpu().numpy(), l.cpu().numpy(), sd.cpu().numpy()
     for b in range(B):
         conv = oracle.CartesianFrenetConverter(egos[b, 0], egos[b, 1], lines[b][0], lines[b][1], 0.0)
-        close(t.origin[b].cpu().numpy(), [conv.rx_ori, conv.ry_ori])
+        close(t.origin[b, :2].cpu().numpy(), [conv.rx_ori, conv.ry_ori])
+        close(float(t.origin[b, 2]), conv.get_s(lines[b][0][-1]))
         for q in range(b * n_per, b * n_per + 60):
             want = conv.cartesian_to_frenet(pts[q, 0], pts[q, 1], vel[q, 0], vel[q, 1], 1)
             close([s[q], l[q]], want[:2])
@@ -118,3 +122,76 @@ def test_refline_capacity_status():
     assert int(t.status[0]) == _lib.MP_RL_E_CAPACITY and int(t.M[0]) == 0
     s, l = mb.c2f(t, np.array([1.0]), np.array([1.0]), np.array([0]))
     assert np.isnan(float(s[0])) and np.isnan(float(l[0]))
+
+
+def test_f2c_golden():
+    import torch
+    from motion_planning_amd import batch as mb
+    g, n_lines = golden_lines()
+    lines = [(g["l%d_rx" % i], g["l%d_ry" % i]) for i in range(n_lines)]
+    t = build_tables(lines)
+    sl = np.concatenate([g["l%d_f2c_in" % i] for i in range(n_lines)])
+    scn = np.concatenate([np.full(len(g["l%d_f2c_in" % i]), i) for i in range(n_lines)])
+    x, y = mb.f2c(t, sl[:, 0], sl[:, 1], scn)
+    torch.cuda.synchronize()
+    want = np.concatenate([g["l%d_f2c_out" % i] for i in range(n_lines)])
+    close(x.cpu().numpy(), want[:, 0])
+    close(y.cpu().numpy(), want[:, 1])
+
+
+def test_f2c_random_vs_oracle(oracle):
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(9)
+    xs = -2.3 + 4.5 * np.arange(15)
+    lines = [(xs, 0.005 * xs * xs), (xs + 0.77, -0.004 * xs * xs + 0.03 * xs)]
+    egos = np.array([[0.3, -0.2], [1.1, 0.4]])
+    t = build_tables(lines, egos)
+    n = 40
+    s = rng.uniform(-1, 70, 2 * n)
+    l = rng.uniform(-1.5, 1.5, 2 * n)
+    scn = np.repeat([0, 1], n)
+    x, y = mb.f2c(t, s, l, scn)
+    torch.cuda.synchronize()
+    for b in range(2):
+        conv = oracle.CartesianFrenetConverter(egos[b, 0], egos[b, 1], lines[b][0], lines[b][1], 0.0)
+        want = np.array([conv.frenet_to_cartesian(a, c) for a, c in zip(s[scn == b], l[scn == b])])
+        close(x.cpu().numpy()[scn == b], want[:, 0])
+        close(y.cpu().numpy()[scn == b], want[:, 1])
+
+
+def test_curve_eval_golden():
+    """Spline build + array evaluation (with its lagged segment switch) for every
+    recorded curve, values and first derivatives, in one ragged batch."""
+    import torch
+    from motion_planning_amd import batch as mb
+    g = load_golden("primitives.npz")
+    n_c = int(g["n_curves"])
+    nk = max(len(g["cv%d_t" % i]) for i in range(n_c))
+    q_max = max(len(g["cv%d_tt" % i]) for i in range(n_c)) + 3
+    for dt_sel in sorted(set(float(g["cv%d_dtvec" % i][0]) for i in range(n_c))):
+        ids = [i for i in range(n_c) if float(g["cv%d_dtvec" % i][0]) == dt_sel]
+        B = len(ids)
+        kt, kx = np.zeros((B, nk)), np.zeros((B, nk))
+        n_k, vec = np.zeros(B, np.int32), np.zeros(B)
+        query, n_q = np.zeros((B, q_max)), np.zeros(B, np.int32)
+        for b, i in enumerate(ids):
+            t = g["cv%d_t" % i]
+            n_k[b] = len(t)
+            kt[b, :len(t)], kx[b, :len(t)] = t, g["cv%d_x" % i]
+            vec[b] = g["cv%d_dtvec" % i][1]
+            tt = g["cv%d_tt" % i]
+            n_q[b] = len(tt)
+            query[b, :len(tt)] = tt
+        arc = mb.curve_eval(kt, kx, n_k, vec, dt_sel, mb.CURVE_ARC, q_max, want_dx=True)
+        qry = mb.curve_eval(kt, kx, n_k, vec, dt_sel, mb.CURVE_QUERY, q_max, query=query, n_query=n_q, want_dx=True)
+        torch.cuda.synchronize()
+        for b, i in enumerate(ids):
+            tt = g["cv%d_tt" % i]
+            for r in (arc, qry):
+                assert int(r["status"][b]) == 1 and int(r["n"][b]) == len(tt)
+                # the recorded abscissae are get_arange(0, sum T, dt) + t0; the kernel's are
+                # get_arange(t0, t0 + sum T, dt): equal here, compared to rounding
+                close(r["t"][b, :len(tt)].cpu().numpy(), tt)
+                close(r["x"][b, :len(tt)].cpu().numpy(), g["cv%d_arr" % i][0])
+                close(r["dx"][b, :len(tt)].cpu().numpy(), g["cv%d_arr" % i][1])
