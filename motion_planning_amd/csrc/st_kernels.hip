@@ -15,7 +15,7 @@
 #include "mp_device.h"
 
 struct StDev {
-    int32_t n_t, n_s_max, r_max;
+    int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -170,6 +170,96 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
     return m_loc;
 }
 
+// Per-cell interval tables in LDS, [interval][cell].
+struct StTab {
+    double *dn, *cst; // [r_tab][N]
+};
+
+// Bytes of dynamic LDS in front of the cell tables (see st_dp_kernel).
+__host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t)
+{
+    size_t b = ((size_t)12 * N + 2 * r_max + n_t + 8) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
+               2 * sizeof(int);
+    return (b + 15) & ~(size_t)15;
+}
+
+#define ST_SPLIT 8 // lanes per cell
+
+// All cells of time layer i >= 2, ST_SPLIT lanes per cell.
+//
+// A thread per cell leaves most lanes idle (cell j has j+1 predecessors and a
+// wave runs as long as its longest cell).  Here the lanes of a wave hold 8
+// neighbouring cells, and the 8 lanes of a cell take predecessors
+// p = j-r, j-r-8, ... (r = lane within the cell): the waves of a workgroup then
+// carry almost equal work, and neighbouring lanes read neighbouring table
+// entries.  Each lane keeps its own first minimum (walking towards lower p with
+// "<="), the 8 partial results are merged on (cost, p), so the lowest p among
+// equal costs wins exactly as in the reference's list.index(min(...))
+// (speed_planner.py:102-111).  The monotone bound of st_relax_layer ends a
+// lane's walk early; what it skips is strictly worse than that lane's best.
+template <int RT>
+__device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb, int i,
+                                                       int n_s, int N, int R, int d_lim, double m_prev,
+                                                       double *cost_g, int32_t *pre_g)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double ds = a.ds;
+    const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
+    const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
+    const int n1 = n_s - 1;
+    for (int q = tid; q < n_s * R; q += nt) {
+        const int k = q / n_s, j = q - k * n_s;
+        StCell<1>::classify(__dmul_rn((double)j, ds), sh.down[k], sh.up[k], &tb.dn[k * N + j], &tb.cst[k * N + j]);
+    }
+    __syncthreads();
+    const int r = tid & (ST_SPLIT - 1), g = tid / ST_SPLIT, G = nt / ST_SPLIT;
+    double m_loc = MP_INF;
+    for (int jb = 0; jb < n_s; jb += G) {
+        const int j = jb + g;
+        const bool live = j < n_s;
+        double best = MP_INF;
+        int bp = 0x7fffffff;
+        if (live) {
+            StCell<RT> cell;
+            cell.monotone = true;
+#pragma unroll
+            for (int k = 0; k < RT; ++k) {
+                if (k < R) {
+                    cell.dn[k] = tb.dn[k * N + j];
+                    cell.cst[k] = tb.cst[k * N + j];
+                    if (cell.dn[k] != MP_INF && cell.cst[k] != 0.0) cell.monotone = false;
+                } else { cell.dn[k] = MP_INF; cell.cst[k] = 0.0; }
+            }
+            const double s = __dmul_rn((double)j, ds);
+            for (int p = j - r; p >= 0; p -= ST_SPLIT) {
+                const int d = j - p;
+                const double base = __dadd_rn(cell.ob(s, sh.front[d]), sh.speed[d]);
+                if (cell.monotone && d >= d_lim && bp != 0x7fffffff && __dadd_rn(base, m_prev) > best) break;
+                const int pp = pre1[p];
+                const int n = d - (p - pp);
+                double jc;
+                if (i == 2) jc = sh.jerk2[n + n1];
+                else {
+                    const int ppp = pre2[pp];
+                    jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * n1];
+                }
+                const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n1]), jc);
+                const double c = __dadd_rn(tot, sh.cost_prev[p]);
+                if (c <= best) { best = c; bp = p; }
+            }
+        }
+        group_argmin<ST_SPLIT>(best, bp);
+        if (live && r == 0) {
+            sh.cost_cur[j] = best;
+            sh.pre16[(size_t)i * N + j] = (short)bp;
+            if (cost_g) cost_g[(size_t)i * N + j] = best;
+            if (pre_g) pre_g[(size_t)i * N + j] = bp;
+            m_loc = best < m_loc ? best : m_loc;
+        }
+    }
+    return m_loc;
+}
+
 // One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
 //   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
 //   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim
@@ -194,6 +284,10 @@ __global__ void st_dp_kernel(StDev a)
     double *red = last_col + n_t;
     sh.pre16 = (short *)(red + 8);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
+    StTab tb; // placed by offset from smem so the pointers stay LDS pointers
+    const size_t tab_off = st_tab_offset(N, R_max, n_t);
+    tb.dn = smem + tab_off / 8;
+    tb.cst = tb.dn + (size_t)a.r_tab * N;
 
     const double ds = a.ds, dt = a.dt, lim = a.speed_lim;
     const double v0 = a.cur_vel[b];
@@ -269,6 +363,19 @@ __global__ void st_dp_kernel(StDev a)
                 if (pre_g) pre_g[(size_t)i * N + j] = 0;
                 m_loc = best < m_loc ? best : m_loc;
             }
+        } else if (R <= a.r_tab && R <= 8) {
+#define ST_SPLIT_CASE(RT) m_loc = st_relax_layer_split<RT>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
+            switch (R) {
+            case 0: ST_SPLIT_CASE(0); break;
+            case 1: ST_SPLIT_CASE(1); break;
+            case 2: ST_SPLIT_CASE(2); break;
+            case 3: ST_SPLIT_CASE(3); break;
+            case 4: ST_SPLIT_CASE(4); break;
+            case 5: ST_SPLIT_CASE(5); break;
+            case 6: ST_SPLIT_CASE(6); break;
+            default: ST_SPLIT_CASE(8); break;
+            }
+#undef ST_SPLIT_CASE
         } else {
             switch (R) {
             case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
@@ -455,13 +562,16 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 256");
         return MP_E_UNSUPPORTED;
     }
-    StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    // cell tables: as many interval slots as fit next to everything else (at most r_max)
+    int r_tab = r_max > 0 ? r_max : 1;
+    if (r_tab > 8) r_tab = 8; // the split path keeps a cell's intervals in registers
+    while (r_tab > 0 && (size_t)r_tab * n_s_max * 16 > 32 * 1024) --r_tab;
+    StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
-    size_t lds = ((size_t)12 * n_s_max + 2 * a.r_max + n_t + 8) * sizeof(double) +
-                 ((size_t)n_t * n_s_max + 1) * sizeof(short) + 2 * sizeof(int);
-    lds = (lds + 15) & ~(size_t)15;
+    const char *th_env = getenv("MP_ST_THREADS");
+    int threads = th_env ? atoi(th_env) : (n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256));
+    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
-    int threads = n_s_max <= 64 ? 64 : (n_s_max <= 128 ? 128 : 256);
     hipLaunchKernelGGL(st_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return st_launch_check("mp_st_dp");
 }
