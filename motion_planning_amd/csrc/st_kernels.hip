@@ -183,9 +183,7 @@ __host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n
     return (b + 15) & ~(size_t)15;
 }
 
-#define ST_SPLIT 8 // lanes per cell
-
-// All cells of time layer i >= 2, ST_SPLIT lanes per cell.
+// All cells of time layer i >= 2, ST_SPLIT lanes per cell (8 below; 4 on small grids).
 //
 // A thread per cell leaves most lanes idle (cell j has j+1 predecessors and a
 // wave runs as long as its longest cell).  Here the lanes of a wave hold 8
@@ -197,7 +195,7 @@ __host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n
 // equal costs wins exactly as in the reference's list.index(min(...))
 // (speed_planner.py:102-111).  The monotone bound of st_relax_layer ends a
 // lane's walk early; what it skips is strictly worse than that lane's best.
-template <int RT>
+template <int RT, int ST_SPLIT>
 __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb, int i,
                                                        int n_s, int N, int R, int d_lim, double m_prev,
                                                        double *cost_g, int32_t *pre_g)
@@ -364,7 +362,9 @@ __global__ void st_dp_kernel(StDev a)
                 m_loc = best < m_loc ? best : m_loc;
             }
         } else if (R <= a.r_tab && R <= 8) {
-#define ST_SPLIT_CASE(RT) m_loc = st_relax_layer_split<RT>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
+#define ST_SPLIT_CASE(RT)                                                                                   \
+    m_loc = N <= 48 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
+                    : st_relax_layer_split<RT, 8>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
             switch (R) {
             case 0: ST_SPLIT_CASE(0); break;
             case 1: ST_SPLIT_CASE(1); break;
