@@ -9,16 +9,34 @@
 #define MP_WAVE 64
 #define MP_INF (__builtin_huge_val())
 
-// ---- wave-level reductions (64 lanes, butterfly over __shfl_xor) ----------
+// ---- wave-level reductions (64 lanes) ---------------------------------------
 
+// One DPP move of a double (both halves with the same control).  Lanes outside
+// row_mask keep their own value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Minimum over the wave, returned in every lane.  Data-parallel-primitive
+// moves inside the 16-lane rows (quad swaps, half mirror, mirror), row
+// broadcasts across rows, then lane 63 is read back; no LDS traffic.
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double o = __shfl_xor(v, m, MP_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
+    double o;
+    o = dpp_f64<0xB1, 0xF>(v); v = o < v ? o : v;  // quad_perm [1,0,3,2]
+    o = dpp_f64<0x4E, 0xF>(v); v = o < v ? o : v;  // quad_perm [2,3,0,1]
+    o = dpp_f64<0x141, 0xF>(v); v = o < v ? o : v; // row_half_mirror
+    o = dpp_f64<0x140, 0xF>(v); v = o < v ? o : v; // row_mirror
+    o = dpp_f64<0x142, 0xA>(v); v = o < v ? o : v; // row_bcast15 into rows 1 and 3
+    o = dpp_f64<0x143, 0xC>(v); v = o < v ? o : v; // row_bcast31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // First-minimum argmin: lower cost wins, equal costs keep the lower index.

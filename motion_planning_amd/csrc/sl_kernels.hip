@@ -32,8 +32,8 @@
 // obstacle penalty (3e4) turns a single mis-rounded distance into a wrong path.
 #include "mp_device.h"
 
-#define SL_E_REG 8   // (sample, obstacle) pairs kept in registers on the fused path
-#define SL_E_CAP 128 // LDS capacity of the compacted pair list
+#define SL_E_REG 6   // (sample, obstacle) pairs kept in registers on the fused path
+#define SL_E_CAP 48  // LDS capacity of the compacted pair list
 
 struct SlDev {
     mp_sl_batch in;
@@ -104,42 +104,53 @@ __device__ __forceinline__ LayerConst layer_const(const LayerGeom &g, double p1s
     return c;
 }
 
-// Compacts the (sample k, obstacle o) pairs with |x_k - ob_s| < ob_dist into
-// LDS (arbitrary order; the collision test is an OR).  One obstacle per thread;
-// only the samples around the obstacle are visited (the index window is
-// conservative, the test itself uses the exact abscissa).  *n_ent must be 0 on
-// entry; the caller synchronises afterwards.  *n_ent may exceed SL_E_CAP:
-// entries beyond the capacity are dropped and callers fall back to testing
-// every pair directly.
+// Appends the (sample k, obstacle) pairs of one obstacle with |x_k - os| < ob_dist
+// to the LDS pair list (arbitrary order; the collision test is an OR).  Only
+// the samples around the obstacle are visited (the index window is
+// conservative, the test itself uses the exact abscissa).  *n_ent may exceed
+// SL_E_CAP: entries beyond the capacity are dropped and callers fall back to
+// testing every pair directly.
+__device__ __forceinline__ void add_obstacle_entries(int *n_ent, const LayerGeom &g, double p1s, double p2s,
+                                                     double d_s, double *e_h0, double *e_ol, double *e_ds2,
+                                                     double os, double ol, double r, double r2)
+{
+    // samples lie in [p1s, p2s] up to rounding: an obstacle further than
+    // ob_dist (plus slack) from that span cannot produce a pair
+    const double rr = r * 1.000001 + 1e-9;
+    if (os < p1s - rr || os > p2s + rr) return;
+    const double T = p2s - p1s;
+    int k_lo = 0, k_hi = g.K - 1;
+    if (g.K > 8) {
+        const double c = (os - p1s) / d_s, w = r / d_s + 2.0;
+        k_lo = (c - w > 0.0) ? (int)(c - w) : 0;
+        k_hi = (c + w < (double)(g.K - 2)) ? (int)(c + w) : g.K - 2;
+    }
+    auto test = [&](int k) {
+        const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
+        const double ds = x - os;
+        const double ds2 = ds * ds;
+        if (ds2 < r2) {
+            const int slot = atomicAdd(n_ent, 1);
+            if (slot < SL_E_CAP) {
+                e_h0[slot] = basis_h0(x, T);
+                e_ol[slot] = ol;
+                e_ds2[slot] = ds2;
+            }
+        }
+    };
+    for (int k = k_lo; k <= k_hi; ++k) test(k);
+    if (k_hi < g.K - 1) test(g.K - 1); // the appended end point sits off the grid
+}
+
+// Pair list of one layer, obstacles strided over the workgroup starting at
+// o_first.  *n_ent must be 0 on entry; the caller synchronises afterwards.
 __device__ __forceinline__ void build_entries(int *n_ent, const LayerGeom &g, double p1s, double p2s, double d_s,
                                               double *e_h0, double *e_ol, double *e_ds2, const double *ob_s,
-                                              const double *ob_l, int n_ob, double r, double r2)
+                                              const double *ob_l, int n_ob, double r, double r2,
+                                              int o_first = threadIdx.x)
 {
-    const double T = p2s - p1s;
-    for (int o = threadIdx.x; o < n_ob; o += blockDim.x) {
-        const double os = ob_s[o], ol = ob_l[o];
-        int k_lo = 0, k_hi = g.K - 1;
-        if (g.K > 8) {
-            const double c = (os - p1s) / d_s, w = r / d_s + 2.0;
-            k_lo = (c - w > 0.0) ? (int)(c - w) : 0;
-            k_hi = (c + w < (double)(g.K - 2)) ? (int)(c + w) : g.K - 2;
-        }
-        auto test = [&](int k) {
-            const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
-            const double ds = x - os;
-            const double ds2 = ds * ds;
-            if (ds2 < r2) {
-                const int slot = atomicAdd(n_ent, 1);
-                if (slot < SL_E_CAP) {
-                    e_h0[slot] = basis_h0(x, T);
-                    e_ol[slot] = ol;
-                    e_ds2[slot] = ds2;
-                }
-            }
-        };
-        for (int k = k_lo; k <= k_hi; ++k) test(k);
-        if (k_hi < g.K - 1) test(g.K - 1); // the appended end point sits off the grid
-    }
+    for (int o = o_first; o < n_ob; o += blockDim.x)
+        add_obstacle_entries(n_ent, g, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s[o], ob_l[o], r, r2);
 }
 
 // One collision test: sample at l1 + dl*h0 against an obstacle at lateral ol
@@ -217,25 +228,25 @@ __device__ __forceinline__ double edge_closed_form(double dl, double g, double u
 // Source-side per-layer arrays in LDS, 16 B per lane and array so that lanes
 // reading consecutive sources touch every bank once.
 struct SrcSh {
-    double2 *lc; // (lateral offset of the source node, its accumulated cost)
-    double2 *gu; // (straight-edge guide cost, 2*cG*A*(l - mid))
+    double2 *lc;   // (lateral offset of the source node, its accumulated cost)
+    double *g;     // straight-edge guide cost of the source node
+    double mid;    // centre of the source row
+    double two_cga; // 2*cG*A of the layer
 };
 
-// Relaxes target l2 = threadIdx.x of layer s: nearest predecessor first, then
-// outward walks that stop once cS*H*dl^2 alone exceeds the best cost so far.
-// w_inv = 1/(cS*H) with its safety factor, or 0 when the bound does not apply.
+// Relaxes target l2 = threadIdx.x (lateral offset l2v) of layer s: nearest
+// predecessor first, then outward walks that stop once cS*H*dl^2 alone exceeds
+// the best cost so far.  w_inv = 1/(cS*H) with its safety factor, or 0 when
+// the bound does not apply.  Returns the accumulated cost; *bj_out = predecessor.
 template <int NE>
-__device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int n_src, const SrcSh &src,
-                                               const double *lcur_g, double Q, double w_inv, double m_prev,
-                                               double g_max, bool sorted, double pen, const Collider<NE> &col,
-                                               double *cost_cur, unsigned char *idx8)
+__device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, double l2v, double Q, double w_inv,
+                                               double m_prev, double g_max, bool sorted, double pen,
+                                               const Collider<NE> &col, int *bj_out)
 {
-    const int n_l = a.in.n_l, l2 = threadIdx.x;
-    if (l2 >= n_l) return MP_INF;
-    const double l2v = lcur_g[l2];
+    const int l2 = threadIdx.x;
     auto eval = [&](int j, double l1, double cp, double dl) {
-        const double2 gu = src.gu[j];
-        double e = edge_closed_form(dl, gu.x, gu.y, Q);
+        const double ua = src.two_cga * (l1 - src.mid);
+        double e = edge_closed_form(dl, src.g[j], ua, Q);
         e += col.hit(l1, dl) ? pen : 0.0;
         return e + cp;
     };
@@ -271,21 +282,22 @@ __device__ __forceinline__ double relax_target(const SlDev &a, int b, int s, int
         const double c = eval(j, lc.x, lc.y, dl);
         if (c < best) { best = c; bj = j; }
     }
-    cost_cur[l2] = best;
-    idx8[(size_t)s * n_l + l2] = (unsigned char)bj;
-    const size_t o = ((size_t)b * a.in.n_s + s) * n_l + l2;
-    if (a.cost_map) a.cost_map[o] = best;
-    if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
+    *bj_out = bj;
     return best;
 }
 
 // Fused SL plan: one workgroup per scenario (one thread per lane of the lattice)
 // walks the layers; edge costs never leave the chip.  A prologue computes every
-// layer's constants in parallel (one thread per layer); the layer loop then
-// costs two barriers per layer.  Dynamic LDS layout (n_lp = n_l rounded up to even):
-//   cost_cur[n_lp] | lc[n_lp] double2 | gu[n_lp] double2 | layA layQ layW layDelta [n_s] each
-//   e_h0[E_CAP] e_ol[E_CAP] e_ds2[E_CAP] | red_min[8] red_max[8] | layK[n_s] layN[n_s] int
-//   misc[4] int | idx8[n_s*n_l] u8
+// layer's constants in parallel (one thread per layer) and keeps each thread's
+// obstacle in registers.  Inside the layer loop a thread relaxes its target and
+// straight away prepares the next layer's source-side data (its own node as a
+// source, the next pair list) in the other half of double-buffered LDS arrays,
+// so a layer costs one barrier and touches no global memory unless the lateral
+// grid changes from layer to layer (that row is prefetched a layer ahead).
+// Dynamic LDS layout (n_lp = n_l rounded up to even):
+//   lc[2][n_lp] double2 | g[2][n_lp] | layA layQ layW layP2 layMid [n_s] each
+//   ent[2][3][E_CAP] | red[2][8] | layK[n_s] int (K, bit 16: end point appended) | misc[4] int
+//   laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
 __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
@@ -293,26 +305,23 @@ __global__ void sl_plan_kernel(SlDev a)
     const int n_l = a.in.n_l, n_s = a.in.n_s;
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     const int n_lp = (n_l + 1) & ~1; // keeps the double2 arrays 16-byte aligned
-    double *cost_cur = smem;
-    SrcSh src;
-    src.lc = (double2 *)(cost_cur + n_lp);
-    src.gu = src.lc + n_lp;
-    double *layA = (double *)(src.gu + n_lp);
+    double2 *lc_all = (double2 *)smem;
+    double *g_all = (double *)(lc_all + 2 * n_lp);
+    double *layA = g_all + 2 * n_lp;
     double *layQ = layA + n_s;
     double *layW = layQ + n_s;
-    double *layDelta = layW + n_s;
-    double *e_h0 = layDelta + n_s;
-    double *e_ol = e_h0 + SL_E_CAP;
-    double *e_ds2 = e_ol + SL_E_CAP;
-    double *red_min = e_ds2 + SL_E_CAP;
-    double *red_max = red_min + 8;
-    int *layK = (int *)(red_max + 8);
-    int *layN = layK + n_s;
-    int *misc = layN + n_s; // [0] pair count, ping-ponged over [0]/[1]
-    unsigned char *idx8 = (unsigned char *)(misc + 4);
+    double *layP2 = layW + n_s;
+    double *layMid = layP2 + n_s;
+    double *ent = layMid + n_s;
+    double *red = ent + 6 * SL_E_CAP;
+    int *layK = (int *)(red + 16);
+    int *misc = layK + n_s; // pair counters, used round-robin over [0..2]
+    unsigned char *laySorted = (unsigned char *)(misc + 4);
+    unsigned char *idx8 = laySorted + ((n_s + 3) & ~3);
 
     const double *s_layers = a.in.s_layers + (size_t)b * n_s;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
+    const int64_t rstride = a.in.l_rstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
     const int n_ob = a.in.n_ob[b];
@@ -322,16 +331,19 @@ __global__ void sl_plan_kernel(SlDev a)
     const double pen = 3.0 * a.p.no_path_cost, abort_thr = 10.0 * a.p.no_path_cost;
     const int mid_l = a.p.mid_l;
     const double ego_s = a.in.ego_sl[2 * b], ego_l = a.in.ego_sl[2 * b + 1];
+    // this thread's obstacle stays in registers for the whole plan
+    const bool has_ob = tid < n_ob;
+    const double my_os = has_ob ? ob_s[tid] : 0.0, my_ol = has_ob ? ob_l[tid] : 0.0;
 
     // ---- prologue: per-layer constants, one thread per layer ----------------
-    double u_loc = 0.0; // largest |l - mid| over the lattice (bounds every straight-edge cost)
     for (int s = tid; s < n_s; s += nt) {
         const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
         const double p2s = s_layers[s];
         const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
-        layK[s] = g.K;
-        layN[s] = g.n;
-        layDelta[s] = g.delta;
+        layK[s] = g.K < 0 ? g.K : (g.K | ((g.n != g.K) << 16));
+        layP2[s] = p2s;
+        layMid[s] = lbase[(size_t)s * rstride + mid_l];
+        laySorted[s] = 1;
         if (g.K >= 0) {
             const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
             layA[s] = c.A;
@@ -341,90 +353,148 @@ __global__ void sl_plan_kernel(SlDev a)
             layW[s] = (c.cSH > 0.0 && c.Q <= 1e5 * c.cSH) ? (1.0 + 1e-9) / (c.cSH * (1.0 - 1e-9)) : 0.0;
         }
     }
+    if (tid == 0) misc[0] = misc[1] = misc[2] = 0;
+    __syncthreads();
     {
-        const int rows = a.in.l_rstride ? n_s : 1;
+        // largest |l - mid| over the lattice (bounds every straight-edge cost)
+        // and, per lattice row, whether it ascends
+        double u_loc = 0.0;
+        const int rows = rstride ? n_s : 1;
         for (int i = tid; i < rows * n_l; i += nt) {
-            const int row = i / n_l;
-            const double *lr = lbase + (size_t)row * a.in.l_rstride;
-            const double u = fabs(lr[i - row * n_l] - lr[mid_l]);
+            const int row = i / n_l, col = i - row * n_l;
+            const double *lr = lbase + (size_t)row * rstride;
+            const double v = lr[col];
+            const double u = fabs(v - lr[mid_l]);
             u_loc = u > u_loc ? u : u_loc;
+            if (col > 0 && !(lr[col - 1] <= v)) laySorted[row] = 0;
         }
-        u_loc = fabs(ego_l - lbase[(size_t)(n_s - 1) * a.in.l_rstride + mid_l]) > u_loc
-                    ? fabs(ego_l - lbase[(size_t)(n_s - 1) * a.in.l_rstride + mid_l]) : u_loc;
+        const double u_ego = fabs(ego_l - layMid[n_s - 1]);
+        u_loc = u_ego > u_loc ? u_ego : u_loc;
         u_loc = -wave_min_f64(-u_loc);
-        if ((tid & (MP_WAVE - 1)) == 0) red_max[wave] = u_loc;
-        if (tid == 0) misc[0] = misc[1] = 0;
+        if ((tid & (MP_WAVE - 1)) == 0) red[wave] = u_loc;
+    }
+    auto layer_geo = [&](int s) {
+        LayerGeom g;
+        const int kn = layK[s];
+        g.K = kn < 0 ? kn : (kn & 0xffff);
+        g.n = kn < 0 ? 0 : g.K - (kn >> 16);
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        g.delta = (p1s + d_s) - p1s;
+        return g;
+    };
+    // pair list of layer s into half (s & 1) of ent, counter misc[s % 3]
+    auto make_entries = [&](int s, const LayerGeom &g) {
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        const double p2s = layP2[s];
+        double *e_h0 = ent + (s & 1) * 3 * SL_E_CAP, *e_ol = e_h0 + SL_E_CAP, *e_ds2 = e_ol + SL_E_CAP;
+        int *cnt = misc + s % 3;
+        if (has_ob) add_obstacle_entries(cnt, g, p1s, p2s, d_s, e_h0, e_ol, e_ds2, my_os, my_ol, r, r2);
+        build_entries(cnt, g, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r, r2, tid + nt);
+    };
+    // layer 0: the ego is the only source (guide term relative to the last row's
+    // centre, as the reference's index -1 picks it)
+    {
+        const LayerGeom g0 = layer_geo(0);
+        if (g0.K >= 0) {
+            if (tid == 0) {
+                const double u = ego_l - layMid[n_s - 1];
+                lc_all[0] = make_double2(ego_l, 0.0);
+                g_all[0] = guide_straight(u, g0.K, w_d, d_s);
+            }
+            make_entries(0, g0);
+        }
     }
     __syncthreads();
-    double u_max = red_max[0];
-    for (int w = 1; w < nw; ++w) u_max = red_max[w] > u_max ? red_max[w] : u_max;
+    double u_max = red[0];
+    for (int w = 1; w < nw; ++w) u_max = red[w] > u_max ? red[w] : u_max;
     const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
+    __syncthreads(); // red is reused by the layer loop
 
+    const bool is_target = tid < n_l;
+    double l_cur = is_target ? lbase[tid] : 0.0; // row 0, this thread's node
     int status = MP_SL_FOUND;
     int done = 0;
-    double m_prev = 0.0; // minimum accumulated cost over the previous layer
     for (int s = 0; s < n_s; ++s) {
-        LayerGeom geo;
-        geo.K = layK[s];
-        geo.n = layN[s];
-        geo.delta = layDelta[s];
-        if (geo.K < 0) { status = geo.K; break; }
-        const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
-        const double p2s = s_layers[s];
-        const int n_src = (s == 0) ? 1 : n_l;
-        const double *lprev_g = lbase + (size_t)(s == 0 ? n_s - 1 : s - 1) * a.in.l_rstride;
-        const double *lcur_g = lbase + (size_t)s * a.in.l_rstride;
-        const double mid = lprev_g[mid_l];
-        const double A = layA[s], Q = layQ[s], w_inv = layW[s];
-        int *n_ent_sh = misc + (s & 1);
-        // source-side arrays (cost_cur still holds the previous layer's row),
-        // sortedness of the source row, pair list
-        int sorted_loc = 1;
-        for (int j = tid; j < n_src; j += nt) {
-            const double l1 = (s == 0) ? ego_l : lprev_g[j];
-            const double u = l1 - mid;
-            src.lc[j] = make_double2(l1, (s == 0) ? 0.0 : cost_cur[j]);
-            src.gu[j] = make_double2(guide_straight(u, geo.K, w_d, d_s), 2.0 * cG * A * u);
-            if (s > 0 && j > 0 && !(lprev_g[j - 1] <= l1)) sorted_loc = 0;
+        const int buf = s & 1;
+        double m_prev = 0.0; // minimum accumulated cost over the previous layer
+        if (s > 0) {
+            m_prev = red[buf * 8];
+            for (int w = 1; w < nw; ++w) m_prev = red[buf * 8 + w] < m_prev ? red[buf * 8 + w] : m_prev;
+            if (s >= 2 && m_prev > abort_thr) {
+                if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
+                if (a.p.early_exit) break;
+            }
         }
-        build_entries(n_ent_sh, geo, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r, r2);
-        const bool sorted = __syncthreads_and(sorted_loc) != 0;
-        const int n_ent = *n_ent_sh;
-        if (tid == 0) misc[(s + 1) & 1] = 0; // next layer's counter
-        double best;
+        const LayerGeom geo = layer_geo(s);
+        if (geo.K < 0) { status = geo.K; break; }
+        const int n_src = (s == 0) ? 1 : n_l;
+        const int n_ent = misc[s % 3];
+        if (tid == 0) misc[(s + 2) % 3] = 0; // counter of the layer after next
+        // next row of the lateral grid, in flight while this layer is relaxed
+        double l_next = l_cur;
+        if (rstride && is_target && s + 1 < n_s) l_next = lbase[(size_t)(s + 1) * rstride + tid];
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        const double p2s = layP2[s];
+        const double Q = layQ[s], w_inv = layW[s];
+        const bool sorted = s == 0 || laySorted[rstride ? s - 1 : 0] != 0;
+        SrcSh src;
+        src.lc = lc_all + buf * n_lp;
+        src.g = g_all + buf * n_lp;
+        src.mid = layMid[s == 0 ? n_s - 1 : s - 1];
+        src.two_cga = 2.0 * cG * layA[s];
+        const double *e_h0 = ent + buf * 3 * SL_E_CAP, *e_ol = e_h0 + SL_E_CAP, *e_ds2 = e_ol + SL_E_CAP;
+        double best = MP_INF;
+        int bj = 0;
+        if (is_target) {
 #define SL_RELAX(NE)                                                                                     \
     {                                                                                                    \
         Collider<NE> col;                                                                                \
         col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);                    \
-        best = relax_target<NE>(a, b, s, n_src, src, lcur_g, Q, w_inv, m_prev, g_max, sorted, pen, col,  \
-                                cost_cur, idx8);                                                         \
+        best = relax_target<NE>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj);      \
     }
-        switch (n_ent) {
-        case 0: SL_RELAX(0) break;
-        case 1: SL_RELAX(1) break;
-        case 2: SL_RELAX(2) break;
-        case 3: SL_RELAX(3) break;
-        case 4: SL_RELAX(4) break;
-        case 5:
-        case 6: SL_RELAX(6) break;
-        case 7:
-        case 8: SL_RELAX(8) break;
-        default:
-            if (n_ent <= SL_E_CAP) SL_RELAX(-1) else SL_RELAX(-2)
-            break;
-        }
+            switch (n_ent) {
+            case 0: SL_RELAX(0) break;
+            case 1: SL_RELAX(1) break;
+            case 2: SL_RELAX(2) break;
+            case 3: SL_RELAX(3) break;
+            case 4: SL_RELAX(4) break;
+            case 5:
+            case 6: SL_RELAX(6) break;
+            default: // rarely more than 6 pairs: the list is read from LDS
+                if (n_ent <= SL_E_CAP) SL_RELAX(-1) else SL_RELAX(-2)
+                break;
+            }
 #undef SL_RELAX
-        best = wave_min_f64(best);
-        if ((tid & (MP_WAVE - 1)) == 0) red_min[wave] = best;
-        __syncthreads();
-        double m = red_min[0];
-        for (int w = 1; w < nw; ++w) m = red_min[w] < m ? red_min[w] : m;
-        m_prev = m;
-        done = s + 1;
-        if (s >= 1 && m > abort_thr) {
-            if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
-            if (a.p.early_exit) break;
+            idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
+            const size_t o = ((size_t)b * n_s + s) * n_l + tid;
+            if (a.cost_map) a.cost_map[o] = best;
+            if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
+            // this node as a source of the next layer (after the last layer the
+            // row is only read by the end-node search)
+            lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
         }
+        done = s + 1;
+        if (s + 1 < n_s) {
+            const LayerGeom gn = layer_geo(s + 1);
+            if (gn.K >= 0) {
+                if (is_target) {
+                    const double u = l_cur - layMid[s];
+                    g_all[(buf ^ 1) * n_lp + tid] = guide_straight(u, gn.K, w_d, d_s);
+                }
+                make_entries(s + 1, gn);
+            }
+        }
+        best = wave_min_f64(best);
+        if ((tid & (MP_WAVE - 1)) == 0) red[(buf ^ 1) * 8 + wave] = best;
+        __syncthreads();
+        l_cur = l_next;
+    }
+    if (done == n_s && n_s >= 2 && status == MP_SL_FOUND) {
+        // the last layer's abort test
+        const int buf = n_s & 1;
+        double m = red[buf * 8];
+        for (int w = 1; w < nw; ++w) m = red[buf * 8 + w] < m ? red[buf * 8 + w] : m;
+        if (m > abort_thr) status = MP_SL_NOT_FOUND;
     }
     __syncthreads();
     // rows that were never relaxed keep the reference's initial values
@@ -435,11 +505,12 @@ __global__ void sl_plan_kernel(SlDev a)
     }
     if (tid < MP_WAVE) {
         // end node: first argmin of the last row, by one wave
+        const double2 *last = lc_all + (done & 1) * n_lp;
         double c = MP_INF;
         int i = 0x7fffffff;
         if (status == MP_SL_FOUND) {
             for (int l = tid; l < n_l; l += MP_WAVE)
-                if (cost_cur[l] < c) { c = cost_cur[l]; i = l; }
+                if (last[l].y < c) { c = last[l].y; i = l; }
             group_argmin<MP_WAVE>(c, i);
         }
         int32_t *pidx = a.path_idx + (size_t)b * n_s;
@@ -632,9 +703,9 @@ extern void mp_set_error(const char *fmt, ...);
 
 static size_t sl_plan_lds_bytes(int n_s, int n_l)
 {
-    size_t d = (size_t)5 * ((n_l + 1) & ~1) + 4 * (size_t)n_s + 3 * SL_E_CAP + 16;
-    size_t bytes = d * sizeof(double) + (2 * (size_t)n_s + 4) * sizeof(int);
-    bytes += (size_t)n_s * n_l;
+    size_t d = (size_t)6 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 6 * SL_E_CAP + 16;
+    size_t bytes = d * sizeof(double) + ((size_t)n_s + 4) * sizeof(int);
+    bytes += (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
 
