@@ -191,6 +191,42 @@ int mp_c2f_batch(int32_t n_pts, const double *px, const double *py, const double
                  const double *tab_kappa, const int32_t *M, double *s, double *l, double *s_dt,
                  void *stream);
 
+/* obstacle classes written by mp_scene_ingest */
+#define MP_OB_BEHIND 0       /* more than 1 m behind the ego: dropped (robot_map.py:49-50) */
+#define MP_OB_STATIC 1       /* static, within ignore_dist: kept                 */
+#define MP_OB_STATIC_FAR 2   /* static, out of range: dropped                    */
+#define MP_OB_DYNAMIC 3      /* moving, some predicted frame within ignore_dist: kept */
+#define MP_OB_DYNAMIC_FAR 4  /* moving, never within range: dropped              */
+
+/* Replaces RobotMap.add_robot / add_ref_line / add_obstacle
+ * (Planning/Interface/robot_map.py:25-68, with GeneralConverter.world_to_robot /
+ * vel_world_to_robot, Model/general_converter.py:14-26, check_static,
+ * Utils/tool.py:41-42, and DynamicObstacle.get_trajectory / cal_min_dist,
+ * Model/obstacle.py:46-64) for B world-frame scenes.
+ * Inputs: rot [B][4] row-major ego rotation R, trans [B][2] ego position t,
+ * ego_vel_w [B][2]; way_xy [B][way_max][2] lane waypoints (first n_way[b]
+ * used); obstacles ob_pos / ob_vel [B][ob_max][2], ob_rad [B][ob_max]
+ * (first n_ob[b] used); ignore_dist (20), n_frames (11) and dt (0.5) of the
+ * prediction.
+ * Outputs: knots_x / knots_y [B][way_max] (zero beyond n_way[b]); ego_vel_r
+ * [B][2]; kept statics st_pos [B][ob_max][2], st_rad [B][ob_max], n_st [B];
+ * kept dynamics dy_pos [B][ob_max][n_frames][2], dy_vel [B][ob_max][2] (may be
+ * NULL), dy_rad [B][ob_max], n_dy [B], all in input order, slots beyond the
+ * counts untouched; ob_class [B][ob_max] MP_OB_* (may be NULL). */
+int mp_scene_ingest(int32_t B, const double *rot, const double *trans, const double *ego_vel_w,
+                    const double *way_xy, const int32_t *n_way, int32_t way_max,
+                    const double *ob_pos, const double *ob_vel, const double *ob_rad,
+                    const int32_t *n_ob, int32_t ob_max, double ignore_dist, int32_t n_frames,
+                    double dt, double *knots_x, double *knots_y, double *ego_vel_r, double *st_pos,
+                    double *st_rad, int32_t *n_st, double *dy_pos, double *dy_vel, double *dy_rad,
+                    int32_t *n_dy, int32_t *ob_class, void *stream);
+
+/* Replaces RobotMap.path_convert / GeneralConverter.robot_to_world
+ * (robot_map.py:84-91, general_converter.py:19-22) for n_pts points: point i
+ * of scene pt_scn[i] becomes R p + t. */
+int mp_robot_to_world(int32_t n_pts, const double *x, const double *y, const int32_t *pt_scn,
+                      const double *rot, const double *trans, double *wx, double *wy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ MP_OK = 0
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY = 1, 0, -2, -3
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
+MP_OB_BEHIND, MP_OB_STATIC, MP_OB_STATIC_FAR, MP_OB_DYNAMIC, MP_OB_DYNAMIC_FAR = 0, 1, 2, 3, 4
 
 _vp = C.c_void_p
 
@@ -46,6 +47,10 @@ SIGNATURES = {
     "mp_curve_eval": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int32, _vp, _vp,
                                 C.c_int32] + [_vp] * 6),
     "mp_c2f_batch": (C.c_int, [C.c_int32] + [_vp] * 5 + [C.c_int32] + [_vp] * 10),
+    "mp_scene_ingest": (C.c_int, [C.c_int32] + [_vp] * 5 + [C.c_int32] + [_vp] * 4 + [C.c_int32, C.c_double,
+                                                                                         C.c_int32, C.c_double]
+                        + [_vp] * 12),
+    "mp_robot_to_world": (C.c_int, [C.c_int32] + [_vp] * 8),
 }
 
 _lib = None

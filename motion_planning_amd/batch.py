@@ -292,3 +292,56 @@ def curve_eval(knots_t, knots_x, n_knots, vec, dt, mode, q_max, query=None, n_qu
                               _p(query), _p(n_query), q_max, _p(out_t), _p(out_x), _p(out_dx), _p(n_out),
                               _p(status), _stream()), "mp_curve_eval")
     return dict(t=out_t, x=out_x, dx=out_dx, n=n_out, status=status)
+
+
+N_FRAMES = 11  # predicted frames of a moving obstacle: t = 0, 0.5, ..., 5.0 (Model/obstacle.py:46-53)
+
+
+def scene_ingest(rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob, ignore_dist=20.0,
+                 n_frames=N_FRAMES, dt=0.5):
+    """Batched RobotMap.add_robot / add_ref_line / add_obstacle (robot_map.py:25-68):
+    world-frame scenes into the ego frame, obstacles filtered, classified and rolled out.
+
+    rot [B, 2, 2] (or [B, 4]) ego rotation, trans [B, 2], ego_vel_w [B, 2]; way_xy [B, W, 2],
+    n_way [B]; ob_pos / ob_vel [B, O, 2], ob_rad [B, O], n_ob [B].  Returns a dict with
+    knots_x, knots_y [B, W], ego_vel [B, 2], st_pos [B, O, 2], st_rad, n_st, dy_pos
+    [B, O, n_frames, 2], dy_vel [B, O, 2], dy_rad, n_dy, ob_class [B, O]."""
+    rot, trans, ego_vel_w = to_dev(rot).reshape(-1, 4), to_dev(trans).reshape(-1, 2), to_dev(ego_vel_w).reshape(-1, 2)
+    B = rot.shape[0]
+    way_xy = to_dev(way_xy).reshape(B, -1, 2)
+    W = way_xy.shape[1]
+    n_way, n_ob = to_dev(n_way, torch.int32), to_dev(n_ob, torch.int32)
+    ob_pos, ob_vel = to_dev(ob_pos).reshape(B, -1, 2), to_dev(ob_vel).reshape(B, -1, 2)
+    ob_rad = to_dev(ob_rad).reshape(B, -1)
+    O = ob_pos.shape[1]
+    assert ob_vel.shape[1] == O and ob_rad.shape[1] == O
+    dev = rot.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = dict(knots_x=torch.empty((B, W), **f64), knots_y=torch.empty((B, W), **f64),
+               ego_vel=torch.empty((B, 2), **f64), st_pos=torch.zeros((B, O, 2), **f64),
+               st_rad=torch.zeros((B, O), **f64), n_st=torch.empty(B, **i32),
+               dy_pos=torch.zeros((B, O, n_frames, 2), **f64), dy_vel=torch.zeros((B, O, 2), **f64),
+               dy_rad=torch.zeros((B, O), **f64), n_dy=torch.empty(B, **i32),
+               ob_class=torch.full((B, O), -1, **i32))
+    check(lib().mp_scene_ingest(B, _p(rot), _p(trans), _p(ego_vel_w), _p(way_xy), _p(n_way), W,
+                                _p(ob_pos) if O else None, _p(ob_vel) if O else None, _p(ob_rad) if O else None,
+                                _p(n_ob), O, float(ignore_dist), int(n_frames), float(dt), _p(out["knots_x"]),
+                                _p(out["knots_y"]), _p(out["ego_vel"]), _p(out["st_pos"]) if O else None,
+                                _p(out["st_rad"]) if O else None, _p(out["n_st"]),
+                                _p(out["dy_pos"]) if O else None, _p(out["dy_vel"]) if O else None,
+                                _p(out["dy_rad"]) if O else None, _p(out["n_dy"]),
+                                _p(out["ob_class"]) if O else None, _stream()), "mp_scene_ingest")
+    return out
+
+
+def robot_to_world(rot, trans, x, y, pt_scn):
+    """Batched RobotMap.path_convert (robot_map.py:84-91): R p + t per point."""
+    rot, trans = to_dev(rot).reshape(-1, 4), to_dev(trans).reshape(-1, 2)
+    x, y = to_dev(x).reshape(-1), to_dev(y).reshape(-1)
+    pt_scn = to_dev(pt_scn, torch.int32).reshape(-1)
+    n = x.numel()
+    wx, wy = torch.empty_like(x), torch.empty_like(y)
+    check(lib().mp_robot_to_world(n, _p(x), _p(y), _p(pt_scn), _p(rot), _p(trans), _p(wx), _p(wy), _stream()),
+          "mp_robot_to_world")
+    return wx, wy

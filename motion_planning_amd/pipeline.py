@@ -39,13 +39,18 @@ def layer_arc_lengths(end_s, d_s=8.0):
 
 def plan_batch(knots_x, knots_y, n_knots, ego_vel, st_pos, st_rad, n_st, dy_pos, dy_rad, n_dy,
                line_vec=None, l_width=3.5, save_width=0.6, n_l=5, speed_lim=25.0 * 5.0 / 18.0, plan_time=5,
-               want_maps=False):
+               want_maps=False, path_planner="dp"):
     """Plans B scenes given in the robot frame (ego at the origin).
 
     knots_x / knots_y [B, nk]; n_knots [B]; ego_vel [B, 2]; statics st_pos [B, Ns, 2],
     st_rad [B, Ns], n_st [B]; dynamics dy_pos [B, Nd, 11, 2] (predicted frames),
-    dy_rad [B, Nd], n_dy [B].  Returns a dict of tensors / lists; `status` [B] is
-    PIPE_OK, PIPE_NOT_FOUND or a negative PIPE_* code."""
+    dy_rad [B, Nd], n_dy [B].  path_planner "dp" runs the SL lattice DP (PathPlanner),
+    "track" follows the lattice's centre lane (TrackPathPlanner, the planner the
+    reference's PlannerInterface.path_plan instantiates, planner_interface.py:133-138).
+    Returns a dict of tensors / lists; `status` [B] is PIPE_OK, PIPE_NOT_FOUND or a
+    negative PIPE_* code."""
+    if path_planner not in ("dp", "track"):
+        raise ValueError("path_planner must be 'dp' or 'track'")
     dev = mb._dev()
     f64 = dict(dtype=torch.float64, device=dev)
     knots_x, knots_y = mb.to_dev(knots_x), mb.to_dev(knots_y)
@@ -117,6 +122,11 @@ def plan_batch(knots_x, knots_y, n_knots, ego_vel, st_pos, st_rad, n_st, dy_pos,
         sel = torch.as_tensor(ids, device=dev)
         lay = torch.as_tensor(np.array([layers[i] for i in np.flatnonzero(n_s_of[ok] == n_s)]), **f64)
         s_layers[sel, :n_s] = lay
+        if path_planner == "track":
+            # every layer's centre node, always "found" (track_path_planner.py:25-35)
+            path_idx[sel, :n_s] = int((n_l - 1) / 2)
+            sl_status[sel] = _lib.MP_SL_FOUND
+            continue
         sb = mb.SLBatch(lay, l_row[None].expand(len(ids), n_l).contiguous(), res["ego_sl"][sel], kept_s[sel],
                         kept_l[sel], n_keep[sel], ob_dist[sel])
         out = mb.sl_plan(sb, mb.sl_params(n_l=n_l), want_maps=want_maps)
@@ -191,3 +201,27 @@ def tables_select(t, sel):
               "inv_y", "inv_theta", "n_inv"):
         setattr(out, k, getattr(t, k)[sel].contiguous())
     return out
+
+
+def plan_world_batch(rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob, ignore_dist=20.0,
+                     **plan_args):
+    """World-frame scenes end to end: what PlannerInterface.run_step computes between
+    coor_trans and the two path_convert calls (planner_interface.py:54-68) for B scenes.
+
+    rot [B, 2, 2] ego rotation, trans [B, 2] ego position, ego_vel_w [B, 2]; way_xy
+    [B, W, 2] lane waypoints ahead, n_way [B]; obstacles ob_pos / ob_vel [B, O, 2],
+    ob_rad [B, O], n_ob [B], all in the world frame.  Returns plan_batch's dict plus
+    `scene` (the ingested robot-frame scene) and `world_x` / `world_y` [F, q_max], the
+    final path of the found scenes in the world frame."""
+    sc = mb.scene_ingest(rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob, ignore_dist)
+    res = plan_batch(sc["knots_x"], sc["knots_y"], n_way, sc["ego_vel"], sc["st_pos"], sc["st_rad"], sc["n_st"],
+                     sc["dy_pos"], sc["dy_rad"], sc["n_dy"], **plan_args)
+    res["scene"] = sc
+    if "final_x" in res:
+        fs = res["found_ids"]
+        F, q_max = res["final_x"].shape
+        rot_d, trans_d = mb.to_dev(rot).reshape(-1, 4)[fs], mb.to_dev(trans).reshape(-1, 2)[fs]
+        scn = torch.arange(F, dtype=torch.int32, device=fs.device).repeat_interleave(q_max)
+        wx, wy = mb.robot_to_world(rot_d, trans_d, res["final_x"], res["final_y"], scn)
+        res.update(world_x=wx.view(F, q_max), world_y=wy.view(F, q_max))
+    return res

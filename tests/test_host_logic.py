@@ -87,3 +87,60 @@ def test_dynamic_rollout_and_robot_map_filters():
     assert rm.add_obstacle(to_world([24.0, 0.0]), R @ np.array([-3.0, 0.0]), 1.0)  # approaches within 20 m
     assert len(rm.static_ob) == 1 and len(rm.dynamic_ob) == 1
     close(rm.path_convert([np.array([1.0, 0.0])])[0], to_world([1.0, 0.0]))
+
+
+def _local_control_scalar(path, speed, loc, local_ind, min_distance=3.0, replan_ind=10):
+    """Scalar restatement of the target selection in LocalPlanner.local_contorl
+    (reference Planning/Interface/local_planner.py:284-311): returns
+    (tmp_ind, local_ind, re_plan)."""
+    import math
+    dist = lambda p, q: math.sqrt((p[0] - q[0]) ** 2 + (p[1] - q[1]) ** 2)  # noqa: E731
+    re_plan = False
+    if len(speed) == 0 or max(speed) < 0.1 or dist(path[0], path[-1]) < 1.0:
+        tmp_ind = -1
+    elif len(path) == 0:
+        tmp_ind = -1
+    elif local_ind < len(path) - replan_ind:
+        tmp_ind = local_ind
+        for i in range(local_ind, len(path)):
+            if dist(path[i], loc) < min_distance:
+                tmp_ind = i
+        local_ind = tmp_ind
+    else:
+        tmp_ind = len(path) - replan_ind
+        re_plan = True
+    return tmp_ind, local_ind, re_plan
+
+
+def test_select_targets_matches_local_control():
+    from motion_planning_amd.Planning.Interface.planner_interface import select_targets
+    rng = np.random.default_rng(3)
+    B, P = 64, 60
+    n_path = rng.integers(0, P + 1, B)
+    n_path[:4] = [0, 5, 10, 11]
+    px, py, sp = np.zeros((B, P)), np.zeros((B, P)), np.zeros((B, P))
+    veh = np.zeros((B, 2))
+    local = np.zeros(B, np.int64)
+    for b in range(B):
+        n = n_path[b]
+        step = rng.uniform(0.005, 1.2)
+        px[b, :n] = step * np.arange(n) + rng.uniform(-50, 50)
+        py[b, :n] = 0.1 * np.sin(np.arange(n)) + rng.uniform(-50, 50)
+        sp[b, :n] = rng.uniform(0, 7, n) * (rng.random() > 0.15)
+        if n:
+            k = rng.integers(0, n)
+            veh[b] = [px[b, k] + rng.uniform(-2, 2), py[b, k] + rng.uniform(-2, 2)]
+            local[b] = rng.integers(0, n)
+    r = select_targets(px, py, n_path, sp, veh, local)
+    for b in range(B):
+        n = n_path[b]
+        path = [(px[b, i], py[b, i]) for i in range(n)]
+        tmp, loc_new, re_plan = _local_control_scalar(path, list(sp[b, :n]), veh[b], int(local[b]))
+        assert r["ind"][b] == (tmp if tmp >= 0 else -1), b
+        assert r["local_ind"][b] == loc_new, b
+        assert bool(r["replan"][b]) == re_plan, b
+        if tmp >= 0:
+            assert np.array_equal(r["target_xy"][b], path[tmp])
+            assert r["target_speed_kmh"][b] == sp[b, tmp] * 18.0 / 5.0
+        else:
+            assert np.all(np.isnan(r["target_xy"][b])) and r["target_speed_kmh"][b] == 0.0

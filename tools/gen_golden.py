@@ -29,6 +29,7 @@ from Model.curve import Curve, QuinticPoly  # noqa: E402
 from Model.cartesian_frenet_conversion import CartesianFrenetConverter  # noqa: E402
 from Planning.DP_Path.sl_map import SLMap  # noqa: E402
 from Planning.DP_Path.path_planner import PathPlanner  # noqa: E402
+from Planning.DP_Path.track_path_planner import TrackPathPlanner  # noqa: E402
 from Planning.DP_Speed.st_map import STMap, ObState  # noqa: E402
 from Planning.DP_Speed.speed_planner import SpeedPlanner  # noqa: E402
 from Utils.tool import get_arange  # noqa: E402
@@ -385,9 +386,94 @@ def gen_pipe():
     save("pipe.npz", **out)
 
 
+# ---------------------------------------------------------------- world-frame scenes
+def gen_world():
+    """Scenes given in the world frame, run through the sequence of
+    PlannerInterface.run_step (coor_trans, path_plan, speed_plan, both
+    path_convert calls) with the reference's classes; CARLA objects replaced by
+    plain arrays.  Both path planners are recorded."""
+    import math
+    rng = np.random.default_rng(77)
+    out = {}
+    names = []
+    designs = [
+        # curvature, knots, first knot x (robot frame), ego pose (x, y, theta), ego speed (robot frame)
+        dict(c=0.0, nk=7, x0=-2.0, pose=(103.5, -41.25, 0.6), vel=(5.0, 0.0)),
+        dict(c=0.004, nk=12, x0=-2.0, pose=(-220.0, 87.5, 2.4), vel=(6.0, 0.3)),
+        dict(c=-0.003, nk=10, x0=-1.5, pose=(12.0, 300.0, -1.9), vel=(4.0, -0.2)),
+        dict(c=0.002, nk=16, x0=-2.5, pose=(-5.0, -7.0, 3.1), vel=(7.0, 0.1)),
+        dict(c=0.0, nk=9, x0=-2.0, pose=(55.0, 66.0, -0.3), vel=(3.0, 0.0)),
+        dict(c=0.001, nk=8, x0=-2.0, pose=(0.0, 0.0, 0.0), vel=(5.0, 0.0)),
+    ]
+    for si, sc in enumerate(designs):
+        name = "w%d" % si
+        ex, ey, th = sc["pose"]
+        ego_rot = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+        ego_pos = np.array([ex, ey])
+        to_world = lambda p: ego_rot.dot(np.asarray(p, dtype=float)) + ego_pos  # noqa: E731
+        ego_vel = ego_rot.dot(np.array(sc["vel"], dtype=float))
+        xs = np.array([sc["x0"] + 4.5 * i for i in range(sc["nk"])])
+        ref_line = [to_world([x, sc["c"] * x * x]) for x in xs]
+        # obstacles: robot-frame design -> world; classes mixed on purpose
+        obs = []
+        n_ob = [6, 9, 12, 4, 0, 7][si]
+        for k in range(n_ob):
+            kind = k % 6
+            if kind == 0:    # static, near, around the lane
+                pr, vr = (rng.uniform(4, 18), rng.uniform(-2.5, 2.5)), (0.0, 0.0)
+            elif kind == 1:  # dynamic, near
+                pr, vr = (rng.uniform(6, 19), rng.uniform(-3, 3)), (rng.uniform(-2, 2), rng.uniform(-1, 1))
+            elif kind == 2:  # behind the car
+                pr, vr = (rng.uniform(-9, -1.2), rng.uniform(-2, 2)), (0.0, 0.0) if k % 2 else (1.0, 0.0)
+            elif kind == 3:  # static, out of range
+                pr, vr = (rng.uniform(21, 40), rng.uniform(-3, 3)), (0.0, 0.0)
+            elif kind == 4:  # dynamic, starts far and approaches
+                pr, vr = (rng.uniform(22, 30), rng.uniform(-1, 1)), (rng.uniform(-4, -2), 0.0)
+            else:            # dynamic, far and leaving
+                pr, vr = (rng.uniform(21, 30), rng.uniform(-1, 1)), (rng.uniform(1, 3), 0.0)
+            obs.append((to_world(pr), ego_rot.dot(np.array(vr, dtype=float)), float(rng.uniform(0.5, 1.0))))
+        d = dict(ego_pos=ego_pos, ego_theta=np.array(th), ego_rot=ego_rot, ego_vel=ego_vel,
+                 ref_line=np.array(ref_line),
+                 ob_pos=np.array([o[0] for o in obs]).reshape(-1, 2), ob_vel=np.array([o[1] for o in obs]).reshape(-1, 2),
+                 ob_rad=np.array([o[2] for o in obs]))
+        # coor_trans (planner_interface.py:98-131)
+        rm = RobotMap(ego_rot, ego_pos)
+        rm.add_robot(ego_pos, ego_vel, 0.0)
+        rm.add_ref_line(ref_line, 3.5, 5, len(ref_line), 0)
+        near = [bool(quiet(rm.add_obstacle, o[0], o[1], o[2])) for o in obs]
+        d.update(near=np.array(near, dtype=bool), rx=np.array(rm.rx_list), ry=np.array(rm.ry_list),
+                 robot_vel_xy=np.array(rm.robot.vel),
+                 st_pos=np.array([o.ob_pos for o in rm.static_ob]).reshape(-1, 2),
+                 st_rad=np.array([o.ob_dist for o in rm.static_ob]),
+                 dy_pos=np.array([o.ob_pos_list for o in rm.dynamic_ob]).reshape(-1, 11, 2),
+                 dy_vel=np.array([o.ob_vel for o in rm.dynamic_ob]).reshape(-1, 2),
+                 dy_rad=np.array([o.ob_dist for o in rm.dynamic_ob]))
+        sl = quiet(SLMap, rm)
+        for tag, cls in (("track", TrackPathPlanner), ("dp", PathPlanner)):
+            found, curve = quiet(cls(sl).plan)
+            d[tag + "_found"] = np.array(bool(found))
+            if not found:
+                continue
+            # speed_plan (planner_interface.py:140-159)
+            pb = sl.path_sampling(curve)
+            st = STMap(sl.converter, pb[-1][0], 5)
+            st.add_obstacle(pb, sl.st_ob_traj, sl.dy_ob_traj)
+            ss, speed_buff = quiet(SpeedPlanner(st, sl.robot_vel, 25.0 * 5.0 / 18.0).plan)
+            pb2 = sl.path_sampling(curve, False, ss)
+            robot_xy = quiet(sl.path_convert, pb2)
+            world_xy = rm.path_convert(robot_xy)
+            d.update({tag + "_ss": np.array(ss), tag + "_speed": np.array(speed_buff),
+                      tag + "_path_sl": np.array(pb2), tag + "_robot_xy": np.array(robot_xy),
+                      tag + "_world_xy": np.array(world_xy)})
+        print(name, "near", near, "track", bool(d["track_found"]), "dp", bool(d["dp_found"]))
+        out.update(prefixed(name + "_", d))
+        names.append(name)
+    out["cases"] = np.array(names)
+    save("world.npz", **out)
+
+
 if __name__ == "__main__":
-    gen_primitives()
-    gen_c2f()
-    gen_sl()
-    gen_st()
-    gen_pipe()
+    only = sys.argv[1:]
+    for fn in (gen_primitives, gen_c2f, gen_sl, gen_st, gen_pipe, gen_world):
+        if not only or fn.__name__[4:] in only:
+            fn()
