@@ -81,6 +81,70 @@ def test_st_random_vs_oracle(oracle, n_s_hi, B):
     assert torch.equal(out["path_s_ind"], out_nt["path_s_ind"]) and torch.equal(out["path_len"], out_nt["path_len"])
 
 
+@pytest.mark.parametrize("n_s_hi,B,r_max", [(150, 10, 12), (600, 3, 6), (1024, 2, 4)])
+def test_st_many_intervals_and_wide_grids(oracle, n_s_hi, B, r_max):
+    """More than 8 intervals on a layer, and grids too wide for the per-cell
+    interval tables, take the thread-per-cell walk; intervals whose end precedes
+    their start switch the monotone bound off.  Same bits either way."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(n_s_hi + r_max)
+    n_t = 11
+    n_s = np.full(B, n_s_hi, np.int32)
+    n_s[-1] = n_s_hi - 37
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    n_reg[0, 2], n_reg[0, 3], n_reg[0, 4] = r_max, min(8, r_max), min(7, r_max)
+    down = rng.uniform(0, n_s_hi, (B, n_t, r_max))
+    up = down + rng.uniform(0, 12, (B, n_t, r_max))
+    up[0, 5, 0] = down[0, 5, 0] - 6.0      # inverted interval
+    cur = rng.uniform(0, 10, B)
+    out = mb.st_dp(n_s, down, up, n_reg, cur, LIM)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
+        n = n_s[b]
+        same(out["cost"][b, :, :n].cpu().numpy(), ref["cost"], "cost[%d]" % b)
+        same(out["pre"][b, :, :n].cpu().numpy(), ref["pre"], "pre[%d]" % b)
+        plen = int(out["path_len"][b])
+        assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"])
+
+
+def test_st_exact_ties_pick_the_first_predecessor(oracle):
+    """A grid blocked everywhere: every cost carries multiples of 1e8, the small
+    terms are rounded away and several predecessors tie exactly; the first one
+    in the reference's scan order must win."""
+    import torch
+    from motion_planning_amd import batch as mb
+    B, n_t = 3, 11
+    n_s = np.array([33, 64, 97], np.int32)
+    n_reg = np.ones((B, n_t), np.int32)
+    down = np.full((B, n_t, 1), -1.0)
+    up = np.full((B, n_t, 1), 5000.0)
+    cur = np.array([0.0, 5.0, 7.0])
+    out = mb.st_dp(n_s, down, up, n_reg, cur, LIM)
+    torch.cuda.synchronize()
+    tied = 0
+    for b in range(B):
+        ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
+        n = int(n_s[b])
+        same(out["cost"][b, :, :n].cpu().numpy(), ref["cost"], "cost[%d]" % b)
+        same(out["pre"][b, :, :n].cpu().numpy(), ref["pre"], "pre[%d]" % b)
+        # count the cells of layer 2 whose minimum is reached by more than one predecessor
+        # (speed_planner.py:120-160 restated with Python floats, ds = 1, dt = 0.5)
+        c1 = ref["cost"][1]
+        for j in range(n):
+            cs = []
+            for p in range(j + 1):
+                v = 1.0 * (j - p) * 1.0 / 0.5
+                spd = 100 * v * v * 0.5 if v > LIM else -100 * ((v - LIM) / LIM) * 0.5
+                acc = 1.0 * (j - 2 * p) * 1.0 / 0.5 ** 2
+                jk = acc / 0.5
+                cs.append((((1e8 + spd) + acc * acc * 0.5) + jk * jk * 0.5) + c1[p])
+            assert min(cs) == ref["cost"][2][j] and cs.index(min(cs)) == ref["pre"][2][j]
+            tied += cs.count(min(cs)) > 1
+    assert tied > 0     # the data really contains exact ties
+
+
 def test_st_other_grid_steps(oracle):
     """ds/dt other than the defaults go through the same tables."""
     import torch
