@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 100
+#define MP_VERSION 110
 
 /* host-side return codes */
 #define MP_OK 0
@@ -41,6 +41,7 @@ extern "C" {
 #define MP_SL_E_EMPTY_EDGE (-2) /* a layer gap shorter than d_s with obstacles present:
                                    the reference raises ValueError (min of empty) */
 #define MP_SL_E_CAPACITY (-3) /* more than MP_SL_K_CAP samples on one edge        */
+#define MP_SL_SKIPPED (-4)    /* the scenario's layer count is 0: nothing was planned */
 #define MP_SL_K_CAP 128
 
 /* per-scenario status written by mp_st_regions */
@@ -67,7 +68,12 @@ typedef struct mp_sl_params {
  * samples are l_map[b*l_bstride + s*l_rstride + l] (l_rstride = 0 when every
  * layer shares one row).  Obstacles are struct-of-arrays, ob_stride slots per
  * scenario of which the first n_ob[b] are used; ob_dist[b] is the single
- * collision radius (sl_map.py:94,106). */
+ * collision radius (sl_map.py:94,106).  SLMap derives the layer count from the
+ * length of the reference line (sl_map.py:61-68), so scenarios of one batch may
+ * use fewer than n_s layers: n_layers[b] (NULL = every scenario uses n_s) is
+ * the count of scenario b, array strides stay n_s, the unused tail of every
+ * output row keeps the initial values (cost 0, index -2, path -1), and a count
+ * of 0 skips the scenario with status MP_SL_SKIPPED. */
 typedef struct mp_sl_batch {
     int32_t B, n_s, n_l, ob_stride;
     const double *s_layers;  /* [B][n_s]                    */
@@ -78,6 +84,7 @@ typedef struct mp_sl_batch {
     const double *ob_l;      /* [B][ob_stride]              */
     const int32_t *n_ob;     /* [B]                         */
     const double *ob_dist;   /* [B]                         */
+    const int32_t *n_layers; /* [B] or NULL                 */
 } mp_sl_batch;
 
 int mp_version(void);
@@ -107,8 +114,9 @@ int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *params, double
 /* Replaces PathPlanner.find_path/find_path_point (path_planner.py:66-101) over
  * a materialised edge-cost tensor: layer-wise min-relaxation with first-minimum
  * predecessor, abort test, end-node argmin and backtrack.  index_map is
- * required (the backtrack reads it). Any n_l, n_s. */
-int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const double *edge_cost,
+ * required (the backtrack reads it). Any n_l, n_s; n_layers [B] as in
+ * mp_sl_batch (may be NULL). */
+int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const int32_t *n_layers, const double *edge_cost,
              const mp_sl_params *params, double *cost_map, int32_t *index_map, int32_t *path_idx,
              int32_t *status, int32_t *layers_done, double *best_cost, void *stream);
 

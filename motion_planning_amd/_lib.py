@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
-MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY = 1, 0, -2, -3
+MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
 MP_OB_BEHIND, MP_OB_STATIC, MP_OB_STATIC_FAR, MP_OB_DYNAMIC, MP_OB_DYNAMIC_FAR = 0, 1, 2, 3, 4
@@ -28,7 +28,8 @@ class SlParams(C.Structure):
 class SlBatch(C.Structure):
     _fields_ = [("B", C.c_int32), ("n_s", C.c_int32), ("n_l", C.c_int32), ("ob_stride", C.c_int32),
                 ("s_layers", _vp), ("l_map", _vp), ("l_bstride", C.c_int64), ("l_rstride", C.c_int64),
-                ("ego_sl", _vp), ("ob_s", _vp), ("ob_l", _vp), ("n_ob", _vp), ("ob_dist", _vp)]
+                ("ego_sl", _vp), ("ob_s", _vp), ("ob_l", _vp), ("n_ob", _vp), ("ob_dist", _vp),
+                ("n_layers", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/mplattice.h declares
@@ -37,7 +38,7 @@ SIGNATURES = {
     "mp_last_error": (C.c_char_p, []),
     "mp_sl_plan": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 7),
     "mp_sl_edge_cost": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams), _vp, _vp, _vp]),
-    "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, C.POINTER(SlParams)] + [_vp] * 7),
+    "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, _vp, C.POINTER(SlParams)] + [_vp] * 7),
     "mp_st_dp": (C.c_int, [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp] + [C.c_double] * 3 + [_vp] * 5),
     "mp_st_regions": (C.c_int, [C.c_int32] * 2 + [_vp] * 3 + [C.c_int32] + [_vp] * 4 + [C.c_int32] + [_vp] * 4
                       + [C.c_int32] * 2 + [_vp] * 5),

@@ -47,10 +47,12 @@ class SLBatch:
     """Device-resident SL lattices + obstacles of B scenarios (struct of arrays).
 
     s_layers [B, n_s]; l_map [B, n_l] (one row shared by all layers) or
-    [B, n_s, n_l]; ego_sl [B, 2]; ob_s / ob_l [B, ob_stride]; n_ob [B]; ob_dist [B].
+    [B, n_s, n_l]; ego_sl [B, 2]; ob_s / ob_l [B, ob_stride]; n_ob [B]; ob_dist [B];
+    n_layers [B] (optional): layers scenario b uses out of the n_s slots.
+    check=False skips the host-side look at n_ob (no device->host read).
     """
 
-    def __init__(self, s_layers, l_map, ego_sl, ob_s, ob_l, n_ob, ob_dist):
+    def __init__(self, s_layers, l_map, ego_sl, ob_s, ob_l, n_ob, ob_dist, n_layers=None, check=True):
         self.s_layers = to_dev(s_layers)
         self.l_map = to_dev(l_map)
         self.ego_sl = to_dev(ego_sl)
@@ -71,13 +73,16 @@ class SLBatch:
             self.ob_l = torch.zeros_like(self.ob_s)
         self.n_ob = to_dev(n_ob, torch.int32)
         self.ob_dist = to_dev(ob_dist)
+        self.n_layers = to_dev(n_layers, torch.int32) if n_layers is not None else None
         assert self.ego_sl.shape == (self.B, 2) and self.n_ob.shape == (self.B,) and self.ob_dist.shape == (self.B,)
-        assert int(self.n_ob.max()) <= self.ob_stride if self.ob_stride else int(self.n_ob.max()) == 0
+        assert self.n_layers is None or self.n_layers.shape == (self.B,)
+        if check:
+            assert int(self.n_ob.max()) <= self.ob_stride if self.ob_stride else int(self.n_ob.max()) == 0
 
     def c_struct(self):
         return SlBatch(self.B, self.n_s, self.n_l, self.ob_stride, _p(self.s_layers), _p(self.l_map),
                        self.l_bstride, self.l_rstride, _p(self.ego_sl), _p(self.ob_s), _p(self.ob_l),
-                       _p(self.n_ob), _p(self.ob_dist))
+                       _p(self.n_ob), _p(self.ob_dist), _p(self.n_layers))
 
     def n_edges(self):
         """Lattice edges per scenario: n_l ego edges + (n_s-1)*n_l^2."""
@@ -120,11 +125,13 @@ def sl_edge_cost(batch, params=None):
     return edge, status
 
 
-def sl_dp(edge_cost, params, out=None):
+def sl_dp(edge_cost, params, out=None, n_layers=None):
     """Layer-wise min-relaxation over materialised edge costs (path_planner.py:66-101)."""
     B, n_s, n_l, _ = edge_cost.shape
     out = out or SLPlanOut(B, n_s, n_l, True, edge_cost.device)
-    check(lib().mp_sl_dp(B, n_s, n_l, _p(edge_cost), C.byref(params), _p(out.cost_map), _p(out.index_map),
+    n_layers = to_dev(n_layers, torch.int32) if n_layers is not None else None
+    check(lib().mp_sl_dp(B, n_s, n_l, _p(n_layers), _p(edge_cost), C.byref(params), _p(out.cost_map),
+                         _p(out.index_map),
                          _p(out.path_idx), _p(out.status), _p(out.layers_done), _p(out.best_cost), _stream()),
           "mp_sl_dp")
     return out

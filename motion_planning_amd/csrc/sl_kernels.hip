@@ -286,6 +286,30 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     return best;
 }
 
+// Layers scenario b uses: all n_s slots, or its own count when the batch has one.
+__device__ __forceinline__ int scenario_layers(const mp_sl_batch &in, int b)
+{
+    if (!in.n_layers) return in.n_s;
+    const int n = in.n_layers[b];
+    return n < 0 ? 0 : (n > in.n_s ? in.n_s : n);
+}
+
+// Outputs of a scenario with no layers: initial maps, no path, MP_SL_SKIPPED.
+__device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, int n_l)
+{
+    for (int i = threadIdx.x; i < n_sm * n_l; i += blockDim.x) {
+        const size_t o = (size_t)b * n_sm * n_l + i;
+        if (a.cost_map) a.cost_map[o] = 0.0;
+        if (a.index_map) a.index_map[o] = -2;
+    }
+    for (int q = threadIdx.x; q < n_sm; q += blockDim.x) a.path_idx[(size_t)b * n_sm + q] = -1;
+    if (threadIdx.x == 0) {
+        a.status[b] = MP_SL_SKIPPED;
+        a.layers_done[b] = 0;
+        if (a.best_cost) a.best_cost[b] = __builtin_nan("");
+    }
+}
+
 // Fused SL plan: one workgroup per scenario (one thread per lane of the lattice)
 // walks the layers; edge costs never leave the chip.  A prologue computes every
 // layer's constants in parallel (one thread per layer) and keeps each thread's
@@ -302,24 +326,29 @@ __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int n_l = a.in.n_l, n_s = a.in.n_s;
+    const int n_l = a.in.n_l, n_sm = a.in.n_s; // n_sm: layer slots per scenario in every array
+    const int n_s = scenario_layers(a.in, b);  // layers this scenario uses
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     const int n_lp = (n_l + 1) & ~1; // keeps the double2 arrays 16-byte aligned
     double2 *lc_all = (double2 *)smem;
     double *g_all = (double *)(lc_all + 2 * n_lp);
     double *layA = g_all + 2 * n_lp;
-    double *layQ = layA + n_s;
-    double *layW = layQ + n_s;
-    double *layP2 = layW + n_s;
-    double *layMid = layP2 + n_s;
-    double *ent = layMid + n_s;
+    double *layQ = layA + n_sm;
+    double *layW = layQ + n_sm;
+    double *layP2 = layW + n_sm;
+    double *layMid = layP2 + n_sm;
+    double *ent = layMid + n_sm;
     double *red = ent + 6 * SL_E_CAP;
     int *layK = (int *)(red + 16);
-    int *misc = layK + n_s; // pair counters, used round-robin over [0..2]
+    int *misc = layK + n_sm; // pair counters, used round-robin over [0..2]
     unsigned char *laySorted = (unsigned char *)(misc + 4);
-    unsigned char *idx8 = laySorted + ((n_s + 3) & ~3);
+    unsigned char *idx8 = laySorted + ((n_sm + 3) & ~3);
 
-    const double *s_layers = a.in.s_layers + (size_t)b * n_s;
+    if (n_s <= 0) { // nothing to plan for this scenario
+        write_skipped(a, b, n_sm, n_l);
+        return;
+    }
+    const double *s_layers = a.in.s_layers + (size_t)b * n_sm;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
     const int64_t rstride = a.in.l_rstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
@@ -466,7 +495,7 @@ __global__ void sl_plan_kernel(SlDev a)
             }
 #undef SL_RELAX
             idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
-            const size_t o = ((size_t)b * n_s + s) * n_l + tid;
+            const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
             if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
             // this node as a source of the next layer (after the last layer the
@@ -498,8 +527,8 @@ __global__ void sl_plan_kernel(SlDev a)
     }
     __syncthreads();
     // rows that were never relaxed keep the reference's initial values
-    for (int i = done * n_l + tid; i < n_s * n_l; i += nt) {
-        size_t o = (size_t)b * n_s * n_l + i;
+    for (int i = done * n_l + tid; i < n_sm * n_l; i += nt) {
+        size_t o = (size_t)b * n_sm * n_l + i;
         if (a.cost_map) a.cost_map[o] = 0.0;
         if (a.index_map) a.index_map[o] = -2;
     }
@@ -513,7 +542,7 @@ __global__ void sl_plan_kernel(SlDev a)
                 if (last[l].y < c) { c = last[l].y; i = l; }
             group_argmin<MP_WAVE>(c, i);
         }
-        int32_t *pidx = a.path_idx + (size_t)b * n_s;
+        int32_t *pidx = a.path_idx + (size_t)b * n_sm;
         if (status == MP_SL_FOUND) {
             if (tid == 0) {
                 int end_l = i;
@@ -523,8 +552,245 @@ __global__ void sl_plan_kernel(SlDev a)
                     pidx[q - 1] = end_l;
                 }
             }
+            for (int q = n_s + tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
         } else {
-            for (int q = tid; q < n_s; q += MP_WAVE) pidx[q] = -1;
+            for (int q = tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
+        }
+        if (tid == 0) {
+            a.status[b] = status;
+            a.layers_done[b] = done;
+            if (a.best_cost) a.best_cost[b] = (status == MP_SL_FOUND) ? c : __builtin_nan("");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Narrow lattices (n_l <= 16, the reference's default is 5 lanes): one lane per
+// EDGE instead of one thread per node.  Lane (t, j) = (tid / W, tid % W), W the
+// power of two >= n_l, holds the edge from source j to target t; the targets'
+// first minima come from a W-lane (cost, index) merge.  Every edge of a layer is
+// evaluated, so no pruning is needed, and the collision test runs obstacle by
+// obstacle for all edges at once: each round the lanes look at 64 obstacles,
+// a ballot keeps those whose arc length lies within ob_dist of the layer's span,
+// and for each of them (a wave-uniform loop) every lane tests its own edge at the
+// samples around the obstacle.  Work per layer is therefore proportional to the
+// obstacles that can touch the layer, however many the scenario has, and all
+// lanes are busy.  Sample abscissae and basis values of the layer sit in LDS,
+// built a layer ahead.  Same edge arithmetic as sl_plan_kernel, bit for bit.
+// Dynamic LDS (n_sm = layer slots):
+//   layA layQ layP2 layMid [n_sm] | xs[2][K_CAP] h0s[2][K_CAP] | lc[2][W] double2
+//   | g[2][W] | red[2][16] | layK[n_sm] int | idx8[n_sm*n_l] u8
+template <int W>
+__global__ void sl_plan_narrow_kernel(SlDev a)
+{
+    extern __shared__ double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
+    const int n_l = a.in.n_l, n_sm = a.in.n_s;
+    const int n_s = scenario_layers(a.in, b);
+    double *layA = smem;
+    double *layQ = layA + n_sm;
+    double *layP2 = layQ + n_sm;
+    double *layMid = layP2 + n_sm;
+    double *xs = layMid + n_sm + (n_sm & 1); // even offset: the double2 array below stays aligned
+    double *h0s = xs + 2 * MP_SL_K_CAP;
+    double2 *lc_all = (double2 *)(h0s + 2 * MP_SL_K_CAP);
+    double *g_all = (double *)(lc_all + 2 * W);
+    double *red = g_all + 2 * W;
+    int *layK = (int *)(red + 32);
+    unsigned char *idx8 = (unsigned char *)(layK + n_sm);
+
+    if (n_s <= 0) {
+        write_skipped(a, b, n_sm, n_l);
+        return;
+    }
+    const double *s_layers = a.in.s_layers + (size_t)b * n_sm;
+    const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
+    const int64_t rstride = a.in.l_rstride;
+    const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
+    const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
+    const int n_ob = a.in.n_ob[b];
+    const double r = a.in.ob_dist[b], r2 = r * r;
+    const double rr = r * 1.000001 + 1e-9; // span test with slack; the pair test itself is exact
+    const double d_s = a.p.d_s, w_d = a.p.w_d;
+    const double inv_ds = 1.0 / d_s, k_half = r * inv_ds + 2.5;
+    const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;
+    const double pen = 3.0 * a.p.no_path_cost, abort_thr = 10.0 * a.p.no_path_cost;
+    const int mid_l = a.p.mid_l;
+    const double ego_s = a.in.ego_sl[2 * b], ego_l = a.in.ego_sl[2 * b + 1];
+    const int t = tid / W, j = tid - t * W;
+
+    for (int s = tid; s < n_s; s += nt) {
+        const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
+        const double p2s = s_layers[s];
+        const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
+        layK[s] = g.K < 0 ? g.K : (g.K | ((g.n != g.K) << 16));
+        layP2[s] = p2s;
+        layMid[s] = lbase[(size_t)s * rstride + mid_l];
+        if (g.K >= 0) {
+            const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
+            layA[s] = c.A;
+            layQ[s] = c.Q;
+        }
+    }
+    __syncthreads();
+    auto layer_geo = [&](int s) {
+        LayerGeom g;
+        const int kn = layK[s];
+        g.K = kn < 0 ? kn : (kn & 0xffff);
+        g.n = kn < 0 ? 0 : g.K - (kn >> 16);
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        g.delta = (p1s + d_s) - p1s;
+        return g;
+    };
+    // abscissae and basis values of layer s into half (s & 1) of the sample tables
+    auto make_samples = [&](int s, const LayerGeom &g) {
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        const double p2s = layP2[s];
+        const double T = p2s - p1s;
+        for (int k = tid; k < g.K; k += nt) {
+            const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
+            xs[(s & 1) * MP_SL_K_CAP + k] = x;
+            h0s[(s & 1) * MP_SL_K_CAP + k] = basis_h0(x, T);
+        }
+    };
+    {
+        const LayerGeom g0 = layer_geo(0);
+        if (g0.K >= 0) {
+            if (tid == 0) {
+                lc_all[0] = make_double2(ego_l, 0.0);
+                g_all[0] = guide_straight(ego_l - layMid[n_s - 1], g0.K, w_d, d_s);
+            }
+            make_samples(0, g0);
+        }
+    }
+    __syncthreads();
+
+    int status = MP_SL_FOUND, done = 0;
+    for (int s = 0; s < n_s; ++s) {
+        const int buf = s & 1;
+        if (s > 0) {
+            double m_prev = red[buf * 16];
+            for (int w = 1; w < nw; ++w) m_prev = red[buf * 16 + w] < m_prev ? red[buf * 16 + w] : m_prev;
+            if (s >= 2 && m_prev > abort_thr) {
+                if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
+                if (a.p.early_exit) break;
+            }
+        }
+        const LayerGeom geo = layer_geo(s);
+        if (geo.K < 0) { status = geo.K; break; }
+        const int K = geo.K;
+        const int n_src = (s == 0) ? 1 : n_l;
+        const bool valid = t < n_l && j < n_src;
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        const double p2s = layP2[s];
+        const double l2v = t < n_l ? lbase[(size_t)s * rstride + t] : 0.0;
+        const double2 lcj = valid ? lc_all[buf * W + j] : make_double2(0.0, 0.0);
+        const double gj = valid ? g_all[buf * W + j] : 0.0;
+        const double dl = l2v - lcj.x;
+        const double *x_tab = xs + buf * MP_SL_K_CAP, *h_tab = h0s + buf * MP_SL_K_CAP;
+
+        bool hit = false;
+        for (int o0 = 0; o0 < n_ob; o0 += MP_WAVE) {
+            const int o = o0 + lane;
+            double os = 0.0, ol = 0.0;
+            bool near = false;
+            if (o < n_ob) {
+                os = ob_s[o];
+                ol = ob_l[o];
+                near = !(os < p1s - rr || os > p2s + rr);
+            }
+            unsigned long long m = __ballot(near);
+            while (m) {
+                const int sl = __builtin_ctzll(m);
+                m &= m - 1;
+                const double uos = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(os), sl),
+                                                    __builtin_amdgcn_readlane(__double2loint(os), sl));
+                const double uol = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ol), sl),
+                                                    __builtin_amdgcn_readlane(__double2loint(ol), sl));
+                // samples that can lie within ob_dist of the obstacle (a generous index
+                // window on the regular grid; the appended end point is tested on its own)
+                int k_lo = 0, k_hi = K - 1;
+                if (K > 8) {
+                    const double c = (uos - p1s) * inv_ds;
+                    k_lo = (c - k_half > 0.0) ? (int)(c - k_half) : 0;
+                    k_hi = (c + k_half < (double)(K - 2)) ? (int)(c + k_half) : K - 2;
+                    k_lo = __builtin_amdgcn_readfirstlane(k_lo);
+                    k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+                }
+                for (int k = k_lo; k <= k_hi; ++k) {
+                    const double ds = x_tab[k] - uos;
+                    const double ds2 = ds * ds;
+                    if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[k], uol, ds2, r2);
+                }
+                if (k_hi < K - 1) {
+                    const double ds = x_tab[K - 1] - uos;
+                    const double ds2 = ds * ds;
+                    if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[K - 1], uol, ds2, r2);
+                }
+            }
+        }
+
+        const double mid = layMid[s == 0 ? n_s - 1 : s - 1];
+        const double two_cga = 2.0 * cG * layA[s];
+        double e = edge_closed_form(dl, gj, two_cga * (lcj.x - mid), layQ[s]);
+        e += hit ? pen : 0.0;
+        double c = valid ? e + lcj.y : MP_INF;
+        int bj = valid ? j : 0x7fffffff;
+        group_argmin<W>(c, bj);
+        const bool owner = j == 0 && t < n_l;
+        if (owner) {
+            idx8[(size_t)s * n_l + t] = (unsigned char)bj;
+            const size_t o = ((size_t)b * n_sm + s) * n_l + t;
+            if (a.cost_map) a.cost_map[o] = c;
+            if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
+            lc_all[(buf ^ 1) * W + t] = make_double2(l2v, c);
+        }
+        done = s + 1;
+        if (s + 1 < n_s) {
+            const LayerGeom gn = layer_geo(s + 1);
+            if (gn.K >= 0) {
+                if (owner) g_all[(buf ^ 1) * W + t] = guide_straight(l2v - layMid[s], gn.K, w_d, d_s);
+                make_samples(s + 1, gn);
+            }
+        }
+        const double bm = wave_min_f64(owner ? c : MP_INF);
+        if (lane == 0) red[(buf ^ 1) * 16 + wave] = bm;
+        __syncthreads();
+    }
+    if (done == n_s && n_s >= 2 && status == MP_SL_FOUND) {
+        const int buf = n_s & 1;
+        double m = red[buf * 16];
+        for (int w = 1; w < nw; ++w) m = red[buf * 16 + w] < m ? red[buf * 16 + w] : m;
+        if (m > abort_thr) status = MP_SL_NOT_FOUND;
+    }
+    __syncthreads();
+    for (int i = done * n_l + tid; i < n_sm * n_l; i += nt) {
+        const size_t o = (size_t)b * n_sm * n_l + i;
+        if (a.cost_map) a.cost_map[o] = 0.0;
+        if (a.index_map) a.index_map[o] = -2;
+    }
+    if (tid < MP_WAVE) {
+        const double2 *last = lc_all + (done & 1) * W;
+        double c = MP_INF;
+        int i = 0x7fffffff;
+        if (status == MP_SL_FOUND) {
+            if (tid < n_l) { c = last[tid].y; i = tid; }
+            group_argmin<MP_WAVE>(c, i);
+        }
+        int32_t *pidx = a.path_idx + (size_t)b * n_sm;
+        if (status == MP_SL_FOUND) {
+            if (tid == 0) {
+                int end_l = i;
+                pidx[n_s - 1] = end_l;
+                for (int q = n_s - 1; q >= 1; --q) {
+                    end_l = idx8[(size_t)q * n_l + end_l];
+                    pidx[q - 1] = end_l;
+                }
+            }
+            for (int q = n_s + tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
+        } else {
+            for (int q = tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
         }
         if (tid == 0) {
             a.status[b] = status;
@@ -543,8 +809,14 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     __shared__ LayerConst lay;
     __shared__ int n_ent_sh;
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int n_l = a.in.n_l, n_s = a.in.n_s;
-    const double *s_layers = a.in.s_layers + (size_t)b * n_s;
+    const int n_l = a.in.n_l, n_sm = a.in.n_s;
+    const int n_s = scenario_layers(a.in, b);
+    double *out = a.edge_cost + ((size_t)b * n_sm + s) * n_l * n_l;
+    if (s >= n_s) { // layer slot this scenario does not use
+        for (int e = tid; e < n_l * n_l; e += nt) out[e] = __builtin_nan("");
+        return;
+    }
+    const double *s_layers = a.in.s_layers + (size_t)b * n_sm;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
@@ -559,7 +831,6 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     const double *lprev_g = lbase + (size_t)(s == 0 ? n_s - 1 : s - 1) * a.in.l_rstride;
     const double *lcur_g = lbase + (size_t)s * a.in.l_rstride;
     const double mid = lprev_g[a.p.mid_l];
-    double *out = a.edge_cost + ((size_t)b * n_s + s) * n_l * n_l;
     const LayerGeom geo = layer_geom(p1s, p2s, d_s, n_ob);
     if (geo.K < 0) {
         if (tid == 0) atomicMin(&a.status[b], geo.K);
@@ -608,16 +879,30 @@ __device__ __forceinline__ double block_min(double v, double *red)
 // scenario; each wave owns target rows, its 64 lanes stride over the sources
 // (coalesced reads) and the row's first-minimum is found with a wave-level
 // shuffle argmin.  LDS: cost_prev[n_l] cost_cur[n_l] red[16].
-__global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_params p, double *cost_map,
-                             int32_t *index_map, int32_t *path_idx, int32_t *status_out,
-                             int32_t *layers_done, double *best_cost)
+__global__ void sl_dp_kernel(int n_sm, int n_l, const int32_t *n_layers, const double *edge_cost,
+                             mp_sl_params p, double *cost_map, int32_t *index_map, int32_t *path_idx,
+                             int32_t *status_out, int32_t *layers_done, double *best_cost)
 {
     extern __shared__ double smem[];
     double *cost_prev = smem, *cost_cur = smem + n_l, *red = cost_cur + n_l;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
-    const double *ec = edge_cost + (size_t)b * n_s * n_l * n_l;
-    int32_t *imap = index_map + (size_t)b * n_s * n_l;
+    const int n_s = n_layers ? min(max(n_layers[b], 0), n_sm) : n_sm;
+    const double *ec = edge_cost + (size_t)b * n_sm * n_l * n_l;
+    int32_t *imap = index_map + (size_t)b * n_sm * n_l;
+    if (n_s <= 0) {
+        for (int i = tid; i < n_sm * n_l; i += nt) {
+            if (cost_map) cost_map[(size_t)b * n_sm * n_l + i] = 0.0;
+            imap[i] = -2;
+        }
+        for (int q = tid; q < n_sm; q += nt) path_idx[(size_t)b * n_sm + q] = -1;
+        if (tid == 0) {
+            status_out[b] = MP_SL_SKIPPED;
+            layers_done[b] = 0;
+            if (best_cost) best_cost[b] = __builtin_nan("");
+        }
+        return;
+    }
     const double abort_thr = 10.0 * p.no_path_cost;
     int status = MP_SL_FOUND, done = 0;
     for (int s = 0; s < n_s; ++s) {
@@ -647,7 +932,7 @@ __global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_pa
         double m = MP_INF;
         for (int l = tid; l < n_l; l += nt) {
             double v = cost_cur[l];
-            if (cost_map) cost_map[((size_t)b * n_s + s) * n_l + l] = v;
+            if (cost_map) cost_map[((size_t)b * n_sm + s) * n_l + l] = v;
             cost_prev[l] = v;
             m = v < m ? v : m;
         }
@@ -659,8 +944,8 @@ __global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_pa
         }
     }
     __syncthreads();
-    for (int i = done * n_l + tid; i < n_s * n_l; i += nt) {
-        if (cost_map) cost_map[(size_t)b * n_s * n_l + i] = 0.0;
+    for (int i = done * n_l + tid; i < n_sm * n_l; i += nt) {
+        if (cost_map) cost_map[(size_t)b * n_sm * n_l + i] = 0.0;
         imap[i] = -2;
     }
     __threadfence_block();
@@ -673,7 +958,7 @@ __global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_pa
                 if (cost_prev[l] < c) { c = cost_prev[l]; i = l; }
             group_argmin<MP_WAVE>(c, i);
         }
-        int32_t *pidx = path_idx + (size_t)b * n_s;
+        int32_t *pidx = path_idx + (size_t)b * n_sm;
         if (status == MP_SL_FOUND) {
             if (tid == 0) {
                 int end_l = i;
@@ -685,8 +970,9 @@ __global__ void sl_dp_kernel(int n_s, int n_l, const double *edge_cost, mp_sl_pa
                     pidx[q - 1] = end_l;
                 }
             }
+            for (int q = n_s + tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
         } else {
-            for (int q = tid; q < n_s; q += MP_WAVE) pidx[q] = -1;
+            for (int q = tid; q < n_sm; q += MP_WAVE) pidx[q] = -1;
         }
         if (tid == 0) {
             status_out[b] = status;
@@ -706,6 +992,13 @@ static size_t sl_plan_lds_bytes(int n_s, int n_l)
     size_t d = (size_t)6 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 6 * SL_E_CAP + 16;
     size_t bytes = d * sizeof(double) + ((size_t)n_s + 4) * sizeof(int);
     bytes += (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+static size_t sl_narrow_lds_bytes(int n_s, int n_l, int W)
+{
+    size_t d = (size_t)4 * n_s + (n_s & 1) + 4 * MP_SL_K_CAP + 4 * W + 2 * W + 32;
+    size_t bytes = d * sizeof(double) + (size_t)n_s * sizeof(int) + (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -758,6 +1051,24 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.layers_done = layers_done;
     a.best_cost = best_cost;
     a.edge_cost = nullptr;
+    // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
+    // well (the two must agree bit for bit; used by the tests)
+    const char *narrow_env = getenv("MP_SL_NARROW");
+    const bool narrow_ok = !(narrow_env && atoi(narrow_env) == 0);
+    if (n_l <= 16 && narrow_ok) {
+        const int W = n_l <= 2 ? 2 : (n_l <= 4 ? 4 : (n_l <= 8 ? 8 : 16));
+        const int threads = ((n_l * W + 63) / 64) * 64;
+        const size_t lds = sl_narrow_lds_bytes(n_s, n_l, W);
+        const dim3 grid(batch->B), block(threads);
+        hipStream_t st = (hipStream_t)stream;
+        switch (W) {
+        case 2: hipLaunchKernelGGL(sl_plan_narrow_kernel<2>, grid, block, lds, st, a); break;
+        case 4: hipLaunchKernelGGL(sl_plan_narrow_kernel<4>, grid, block, lds, st, a); break;
+        case 8: hipLaunchKernelGGL(sl_plan_narrow_kernel<8>, grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL(sl_plan_narrow_kernel<16>, grid, block, lds, st, a); break;
+        }
+        return launch_check("mp_sl_plan");
+    }
     const size_t lds = sl_plan_lds_bytes(n_s, n_l);
     const int threads = ((n_l + 63) / 64) * 64;
     hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
@@ -794,10 +1105,10 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     return launch_check("mp_sl_edge_cost");
 }
 
-extern "C" int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const double *edge_cost,
-                        const mp_sl_params *params, double *cost_map, int32_t *index_map,
-                        int32_t *path_idx, int32_t *status, int32_t *layers_done, double *best_cost,
-                        void *stream)
+extern "C" int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const int32_t *n_layers,
+                        const double *edge_cost, const mp_sl_params *params, double *cost_map,
+                        int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+                        double *best_cost, void *stream)
 {
     if (B <= 0 || n_s <= 0 || n_l <= 0) { mp_set_error("non-positive B/n_s/n_l"); return MP_E_BADARG; }
     if (!edge_cost || !params || !index_map || !path_idx || !status || !layers_done) {
@@ -807,7 +1118,7 @@ extern "C" int mp_sl_dp(int32_t B, int32_t n_s, int32_t n_l, const double *edge_
     size_t lds = ((size_t)2 * n_l + 16) * sizeof(double);
     if (lds > 64 * 1024) { mp_set_error("mp_sl_dp: n_l too large"); return MP_E_UNSUPPORTED; }
     int threads = n_l >= 256 ? 512 : 256;
-    hipLaunchKernelGGL(sl_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, n_s, n_l, edge_cost,
-                       *params, cost_map, index_map, path_idx, status, layers_done, best_cost);
+    hipLaunchKernelGGL(sl_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, n_s, n_l, n_layers,
+                       edge_cost, *params, cost_map, index_map, path_idx, status, layers_done, best_cost);
     return launch_check("mp_sl_dp");
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
         assert s in _lib.SIGNATURES, "no ctypes signature for " + s
     assert set(_lib.SIGNATURES) == set(syms)
-    assert L.mp_version() == 100
+    assert L.mp_version() == 110
 
 
 def test_host_side_argument_errors_need_no_gpu():
@@ -36,7 +36,7 @@ def test_host_side_argument_errors_need_no_gpu():
     assert L.mp_sl_plan(None, None, None, None, None, None, None, None, None) == -1
     assert b"null" in L.mp_last_error()
     prm = _lib.SlParams(0.5, 0.5, 1e4, 1, 2)
-    assert L.mp_sl_dp(0, 1, 1, None, C.byref(prm), None, None, None, None, None, None, None) == -1
+    assert L.mp_sl_dp(0, 1, 1, None, None, C.byref(prm), None, None, None, None, None, None, None) == -1
     assert L.mp_st_dp(1, 1, 5, None, None, None, None, 0, None, 1.0, 1.0, 0.5, None, None, None, None, None) == -1
     assert L.mp_c2f_batch(0, *([None] * 5), 4, *([None] * 10)) == -1
 

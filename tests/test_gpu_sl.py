@@ -9,21 +9,31 @@ from parity import assert_costs, assert_sl_parity, pad_obstacles
 pytestmark = pytest.mark.gpu
 
 
-def gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, split=False, shared_row=False):
-    """Runs B scenarios; s_map/l_map [B, n_s, n_l]. Returns list of dicts (numpy)."""
+def gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, split=False, shared_row=False,
+           n_layers=None, per_node=False):
+    """Runs B scenarios; s_map/l_map [B, n_s, n_l]. Returns list of dicts (numpy).
+    per_node: lattices of up to 16 lanes normally take the lane-per-edge kernel; this
+    sends them through the thread-per-node kernel instead."""
+    import os
+    import torch
     from motion_planning_amd import batch as mb
     s_map, l_map = np.asarray(s_map), np.asarray(l_map)
     B, n_s, n_l = s_map.shape
     ob_s, ob_l, n_ob = pad_obstacles(obs)
-    sb = mb.SLBatch(s_map[:, :, 0], l_map[:, 0, :] if shared_row else l_map, ego, ob_s, ob_l, n_ob, ob_dist)
+    sb = mb.SLBatch(s_map[:, :, 0], l_map[:, 0, :] if shared_row else l_map, ego, ob_s, ob_l, n_ob, ob_dist,
+                    n_layers=n_layers)
     prm = mb.sl_params(early_exit=early_exit, mid_l=mid_l)
     if split:
         edge, st = mb.sl_edge_cost(sb, prm)
         assert (st.cpu().numpy() == 1).all()
-        out = mb.sl_dp(edge, prm)
+        out = mb.sl_dp(edge, prm, n_layers=n_layers)
     else:
-        out = mb.sl_plan(sb, prm)
-    import torch
+        if per_node:
+            os.environ["MP_SL_NARROW"] = "0"
+        try:
+            out = mb.sl_plan(sb, prm)
+        finally:
+            os.environ.pop("MP_SL_NARROW", None)
     torch.cuda.synchronize()
     res = []
     for b in range(B):
@@ -115,6 +125,14 @@ RANDOM_SHAPES = [
     (3, 5, 200, 3.0, 10, 0.2, 0.5, None, False),
     (8, 6, 12, 8.0, 40, 0.4, 0.9, 12.0, False),    # many pairs per layer: mask path
     (4, 4, 16, 8.0, 300, 0.8, 1.2, 10.0, False),   # pair list overflows its LDS capacity
+    (6, 5, 20, 8.0, 300, 0.8, 1.2, 14.0, False),   # the same on the thread-per-node kernel
+    (16, 12, 5, 8.0, 900, 0.5, 0.9, None, True),   # default lattice, crowded scene (14 rounds of 64 obstacles)
+    (8, 7, 2, 8.0, 20, 0.5, 0.9, None, True),      # lane-per-edge kernel, groups of 2 lanes
+    (8, 7, 3, 8.0, 20, 0.5, 0.9, None, True),      # groups of 4
+    (8, 9, 8, 4.0, 70, 0.4, 0.8, None, True),      # groups of 8, full
+    (6, 9, 9, 4.0, 70, 0.4, 0.8, None, True),      # groups of 16, three waves
+    (4, 30, 7, 1.5, 100, 0.2, 0.5, None, False),   # thin layers: 4 samples per edge
+    (4, 3, 5, 30.0, 40, 0.5, 0.9, None, True),     # 61 samples per edge
 ]
 
 
@@ -128,6 +146,9 @@ def test_sl_random_vs_oracle(oracle, shape, early_exit):
     res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit)
     res_split, edges = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, split=True)
     res_row = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, shared_row=True)
+    others = [res_split, res_row]
+    if n_l <= 16:
+        others.append(gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, per_node=True))
     n_found = 0
     for b in range(B):
         small = n_s * n_l * n_l <= 40000
@@ -135,8 +156,8 @@ def test_sl_random_vs_oracle(oracle, shape, early_exit):
                                   no_early_exit=not early_exit, want_edges=small)
         assert_sl_parity(res[b], ref, ref.get("edge_cost"))
         n_found += ref["found"]
-        # fused == edge tensor + DP kernel == shared-row layout, bit for bit
-        for other in (res_split[b], res_row[b]):
+        # fused == edge tensor + DP kernel == shared-row layout (== thread-per-node kernel), bit for bit
+        for other in (o[b] for o in others):
             assert np.array_equal(res[b]["cost_map"], other["cost_map"])
             assert np.array_equal(res[b]["index_map"], other["index_map"])
             assert np.array_equal(res[b]["path_idx"], other["path_idx"])
@@ -146,6 +167,39 @@ def test_sl_random_vs_oracle(oracle, shape, early_exit):
             assert_costs(edges[b, 0, :, 0], ref["edge_cost"][0, :, 0])
             assert_costs(edges[b, 1:d], ref["edge_cost"][1:d])
     print("found %d of %d" % (n_found, B))
+
+
+@pytest.mark.parametrize("n_l", [5, 12, 40])
+def test_sl_layer_count_per_scenario(oracle, n_l):
+    """Scenarios of one batch with different layer counts (SLMap derives the count from
+    the reference line's length): each must equal the same scenario planned alone, and
+    the unused tail of every output row keeps the initial values."""
+    from motion_planning_amd import _lib
+    rng = np.random.default_rng(77 + n_l)
+    B, n_sm = 12, 11
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_sm, n_l, 8.0, 14, 0.4, 0.9, None, False)
+    n_layers = rng.integers(1, n_sm + 1, B).astype(np.int32)
+    n_layers[0], n_layers[1], n_layers[2] = n_sm, 0, 1
+    mid_l = int((n_l - 1) / 2)
+    for early in (True, False):
+        res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early, n_layers=n_layers)
+        res_split, _ = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early, n_layers=n_layers, split=True)
+        for b in range(B):
+            n = int(n_layers[b])
+            for r in (res[b], res_split[b]):
+                if n == 0:
+                    assert r["status"] == _lib.MP_SL_SKIPPED and r["layers_done"] == 0
+                    assert (r["path_idx"] == -1).all() and (r["index_map"] == -2).all() and (r["cost_map"] == 0).all()
+                    continue
+                ref = oracle.sl_find_path(s_map[b, :n], l_map[b, :n], mid_l, ego[b], obs[b], ob_dist[b],
+                                          no_early_exit=not early, want_edges=True)
+                got = dict(r, cost_map=r["cost_map"][:n], index_map=r["index_map"][:n], path_idx=r["path_idx"][:n])
+                assert_sl_parity(got, ref, ref.get("edge_cost"))
+                assert (r["cost_map"][n:] == 0).all() and (r["index_map"][n:] == -2).all()
+                assert (r["path_idx"][n:] == -1).all()
+            assert np.array_equal(res[b]["cost_map"], res_split[b]["cost_map"])
+            assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
+            assert np.array_equal(res[b]["path_idx"], res_split[b]["path_idx"])
 
 
 def test_sl_empty_edge_and_capacity_status():
