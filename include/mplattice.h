@@ -235,6 +235,99 @@ int mp_scene_ingest(int32_t B, const double *rot, const double *trans, const dou
 int mp_robot_to_world(int32_t n_pts, const double *x, const double *y, const int32_t *pt_scn,
                       const double *rot, const double *trans, double *wx, double *wy, void *stream);
 
+
+/* ---- whole replan, B scenes per call --------------------------------------
+ * Replaces what PlannerInterface.run_step computes between coor_trans and the
+ * conversion back to the world frame (Planning/Interface/planner_interface.py:
+ * 54-68: path_plan :133-138, speed_plan :140-159, sl_map.path_convert) for B
+ * robot-frame scenes, every stage on the device and nothing read back by the
+ * host in between:
+ *   reference-line tables (CartesianFrenetConverter.__init__) -> ego state and
+ *   every obstacle frame to Frenet, lane filter, obstacle list, lattice layers
+ *   (SLMap.create_frenet_map / add_obstacle, sl_map.py:33-112) -> SL path DP
+ *   (PathPlanner.plan) or the centre lane (TrackPathPlanner.plan) -> path spline
+ *   sampled every 0.5 m (SLMap.path_sampling) -> ST grid size and blocked
+ *   intervals (STMap.__init__ / add_obstacle) -> ST speed DP and the speed
+ *   profile every dt/5 (SpeedPlanner.plan) -> path points at the profile's arc
+ *   lengths (path_sampling(curve, False, ss)) -> Frenet->Cartesian
+ *   (SLMap.path_convert).
+ * All intermediate and final arrays live in ONE caller-owned device arena whose
+ * layout the library defines: mp_plan_array_info() describes array i (name,
+ * element type, shape, byte offset) for the given sizes and
+ * mp_plan_arena_bytes() gives the arena size.  Scene b's slice of every array is
+ * what one reference object would hold; arrays are indexed by scene whether or
+ * not the scene found a path. */
+
+/* per-scene outcome, array "status" */
+#define MP_PLAN_OK 1
+#define MP_PLAN_NOT_FOUND 0        /* PathPlanner.plan returned (False, [])           */
+#define MP_PLAN_E_EMPTY_EDGE (-2)  /* = MP_SL_E_EMPTY_EDGE                            */
+#define MP_PLAN_E_CAPACITY (-3)    /* = MP_SL_E_CAPACITY, or more layers than n_s_max */
+#define MP_PLAN_E_MAP_TOO_BIG (-4) /* sl_map.py:57-60 ValueError                      */
+#define MP_PLAN_E_BAD_LINE (-5)    /* reference-line tables failed (MP_RL_E_*)        */
+#define MP_PLAN_E_ST_CAPACITY (-6) /* ST grid wider than st_n_s_max, more blocked
+                                      intervals than r_max or path longer than p_max  */
+
+/* Robot-frame scenes (what RobotMap holds after coor_trans, robot_map.py:25-68). */
+typedef struct mp_scene_batch {
+    const double *knots_x, *knots_y; /* [B][n_knots_max] reference-line waypoints     */
+    const int32_t *n_knots;          /* [B]                                           */
+    const double *line_vec;          /* [B] end slope of the line (0)                 */
+    const double *ego_vel;           /* [B][2]                                        */
+    const double *st_pos;            /* [B][n_st_max][2] static obstacles             */
+    const double *st_rad;            /* [B][n_st_max]                                 */
+    const int32_t *n_st;             /* [B]                                           */
+    const double *dy_pos;            /* [B][n_dy_max][n_frames][2] predicted frames   */
+    const double *dy_rad;            /* [B][n_dy_max]                                 */
+    const int32_t *n_dy;             /* [B]                                           */
+} mp_scene_batch;
+
+/* Sizes that fix the arena layout. */
+typedef struct mp_plan_dims {
+    int32_t B, n_knots_max, n_st_max, n_dy_max;
+    int32_t n_frames;   /* frames per moving obstacle (11, Model/obstacle.py:46-53)   */
+    int32_t n_l;        /* lateral samples (5, planner_interface.py:100)              */
+    int32_t m_max;      /* reference-line samples per scene (line span / 0.5 + 2)     */
+    int32_t n_s_max;    /* lattice layers per scene (13 for a 100 m map)              */
+    int32_t p_max;      /* path samples per scene (map length / 0.5 + 2)              */
+    int32_t n_t;        /* ST time layers = ceil(plan_time / st_dt) + 1 (11)          */
+    int32_t st_n_s_max; /* ST cells per time layer (map length / st_ds + 1)           */
+    int32_t r_max;      /* blocked intervals per time layer                           */
+    int32_t q_max;      /* speed-profile samples ((n_t - 1) * 5 + 2)                  */
+    int32_t want_maps;  /* 1: keep SL cost_map / index_map and ST cost / pre tables   */
+} mp_plan_dims;
+
+/* Constants of the reference's planner stack; mp_plan_default_params fills in
+ * the values the reference hard-codes. */
+typedef struct mp_plan_params {
+    double l_width, save_width; /* 3.5, 0.6 (planner_interface.py:99, robot_map.py:35) */
+    double layer_gap;           /* 8: SLMap.d_s (sl_map.py:25)                         */
+    double max_map_len;         /* 100 (sl_map.py:57)                                  */
+    double d_x;                 /* 0.5: converter sample spacing (cfc.py:12)           */
+    double path_dt;             /* 0.5: path spline sampling (path_planner.py:53)      */
+    mp_sl_params sl;            /* mid_l < 0: int((n_l-1)/2)                           */
+    double speed_lim;           /* 25*5/18 (planner_interface.py:151)                  */
+    double st_ds, st_dt;        /* 1.0, 0.5 (st_map.py:15-16)                          */
+    int32_t path_planner;       /* 0: SL lattice DP, 1: centre lane                    */
+    int32_t reserved;
+} mp_plan_params;
+
+#define MP_F64 0
+#define MP_I32 1
+
+void mp_plan_default_params(mp_plan_params *params);
+int32_t mp_plan_array_count(void);
+/* Array i of the arena: *name (static string), *dtype MP_F64 / MP_I32, shape[4]
+ * (unused trailing dimensions are 1), *offset in bytes.  Returns MP_OK or
+ * MP_E_BADARG. */
+int mp_plan_array_info(const mp_plan_dims *dims, int32_t i, const char **name, int32_t *dtype,
+                       int64_t shape[4], int64_t *offset);
+int64_t mp_plan_arena_bytes(const mp_plan_dims *dims);
+/* Enqueues the whole chain on `stream`.  arena: device memory of at least
+ * mp_plan_arena_bytes(dims) bytes, 256-byte aligned. */
+int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                   void *arena, int64_t arena_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,16 +88,11 @@ class PlannerInterface:
         self.result = res
         self.status = res["status"].cpu().numpy()
         out = [([], []) for _ in self.scenes]
-        if "world_x" not in res:
-            return out
-        found = res["found_ids"].cpu().numpy()
         wx, wy = res["world_x"].cpu().numpy(), res["world_y"].cpu().numpy()
         vv, n_prof = res["vv"].cpu().numpy(), res["n_prof"].cpu().numpy()
-        for k, b in enumerate(found):
-            if self.status[b] != pipeline.PIPE_OK:
-                continue
-            n = int(n_prof[k])
-            out[b] = ([Location(float(wx[k, i]), float(wy[k, i])) for i in range(n)], [float(v) for v in vv[k, :n]])
+        for b in np.flatnonzero(self.status == pipeline.PIPE_OK):
+            n = int(n_prof[b])
+            out[b] = ([Location(float(wx[b, i]), float(wy[b, i])) for i in range(n)], [float(v) for v in vv[b, :n]])
         return out
 
 

@@ -16,6 +16,9 @@ MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPE
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
 MP_OB_BEHIND, MP_OB_STATIC, MP_OB_STATIC_FAR, MP_OB_DYNAMIC, MP_OB_DYNAMIC_FAR = 0, 1, 2, 3, 4
+MP_PLAN_OK, MP_PLAN_NOT_FOUND, MP_PLAN_E_EMPTY_EDGE, MP_PLAN_E_CAPACITY = 1, 0, -2, -3
+MP_PLAN_E_MAP_TOO_BIG, MP_PLAN_E_BAD_LINE, MP_PLAN_E_ST_CAPACITY = -4, -5, -6
+MP_F64, MP_I32 = 0, 1
 
 _vp = C.c_void_p
 
@@ -30,6 +33,23 @@ class SlBatch(C.Structure):
                 ("s_layers", _vp), ("l_map", _vp), ("l_bstride", C.c_int64), ("l_rstride", C.c_int64),
                 ("ego_sl", _vp), ("ob_s", _vp), ("ob_l", _vp), ("n_ob", _vp), ("ob_dist", _vp),
                 ("n_layers", _vp)]
+
+
+class SceneBatch(C.Structure):       # mp_scene_batch
+    _fields_ = [(n, _vp) for n in ("knots_x", "knots_y", "n_knots", "line_vec", "ego_vel", "st_pos", "st_rad",
+                                   "n_st", "dy_pos", "dy_rad", "n_dy")]
+
+
+class PlanDims(C.Structure):         # mp_plan_dims
+    _fields_ = [(n, C.c_int32) for n in ("B", "n_knots_max", "n_st_max", "n_dy_max", "n_frames", "n_l", "m_max",
+                                         "n_s_max", "p_max", "n_t", "st_n_s_max", "r_max", "q_max", "want_maps")]
+
+
+class PlanParams(C.Structure):       # mp_plan_params
+    _fields_ = [("l_width", C.c_double), ("save_width", C.c_double), ("layer_gap", C.c_double),
+                ("max_map_len", C.c_double), ("d_x", C.c_double), ("path_dt", C.c_double), ("sl", SlParams),
+                ("speed_lim", C.c_double), ("st_ds", C.c_double), ("st_dt", C.c_double),
+                ("path_planner", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/mplattice.h declares
@@ -52,6 +72,13 @@ SIGNATURES = {
                                                                                          C.c_int32, C.c_double]
                         + [_vp] * 12),
     "mp_robot_to_world": (C.c_int, [C.c_int32] + [_vp] * 8),
+    "mp_plan_default_params": (None, [C.POINTER(PlanParams)]),
+    "mp_plan_array_count": (C.c_int32, []),
+    "mp_plan_array_info": (C.c_int, [C.POINTER(PlanDims), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mp_plan_arena_bytes": (C.c_int64, [C.POINTER(PlanDims)]),
+    "mp_plan_scenes": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp, C.c_int64,
+                                 _vp]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 // operation order written here (the reference's) is the order executed.
 #pragma clang fp contract(off)
 #include "mp_device.h"
+#include "c2f_device.h"
 
 #define RL_SEG_CAP 128 // spline segments per reference line
 #define RL_ARC_CAP 128 // samples in one rectangle-rule piece
@@ -320,34 +321,20 @@ __global__ void c2f_kernel(C2fDev a)
         if (a.s_dt) a.s_dt[p] = nan;
         return;
     }
-    // Curve.projection + cal_dist_arr: first minimum of the sample distances
-    double best = MP_INF;
-    int k = 0;
-    for (int i = 0; i < M; ++i) {
-        const double dx = tx[i] - x, dy = ty[i] - y;
-        const double d = __dsqrt_rn(dx * dx + dy * dy);
-        if (d < best) { best = d; k = i; }
-    }
-    const double rx = tx[k], ry = ty[k];
-    const double th = a.tab_theta[(size_t)b * a.m_max + k];
-    const double dx = x - rx, dy = y - ry;
-    const double l_sign = (dy * cos(th) - dx * sin(th) > 0) ? 1.0 : -1.0;
-    const double l = l_sign * best;
-    a.s[p] = a.tab_s[(size_t)b * a.m_max + k];
+    const size_t tb = (size_t)b * a.m_max;
+    double s, l;
+    const int k = c2f_point(tx, ty, a.tab_s + tb, a.tab_theta + tb, M, x, y, &s, &l);
+    a.s[p] = s;
     a.l[p] = l;
-    if (a.s_dt) {
-        const double kr = a.tab_kappa[(size_t)b * a.m_max + k];
-        const double vx = a.vx[p], vy = a.vy[p];
-        const double vtheta = atan2(vy, vx);
-        const double speed = __dsqrt_rn(vx * vx + vy * vy);
-        a.s_dt[p] = speed * cos(vtheta - th) / (1 - kr * l);
-    }
+    if (a.s_dt) a.s_dt[p] = c2f_s_dt(a.tab_theta[tb + k], a.tab_kappa[tb + k], l, a.vx[p], a.vy[p]);
 }
 
 struct F2cDev {
     int32_t n_pts, m_max;
     const double *s, *l;
-    const int32_t *pt_scn;
+    const int32_t *pt_scn;      // scene of each point, or null: point p belongs to scene p / pts_per_scn
+    int32_t pts_per_scn;
+    const int32_t *n_valid;     // with pts_per_scn: points of a scene beyond n_valid[scene] give 0 (may be null)
     const double *inv_x, *inv_s, *inv_y, *inv_theta, *origin;
     const int32_t *n_inv;
     double *x, *y;
@@ -360,7 +347,11 @@ __global__ void f2c_kernel(F2cDev a)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_pts) return;
-    const int b = a.pt_scn[p];
+    const int b = a.pt_scn ? a.pt_scn[p] : p / a.pts_per_scn;
+    if (!a.pt_scn && a.n_valid && p - b * a.pts_per_scn >= a.n_valid[b]) {
+        a.x[p] = a.y[p] = 0.0;
+        return;
+    }
     const int n = a.n_inv[b];
     const double s = a.s[p], l = a.l[p];
     const double *arc = a.inv_s + (size_t)b * a.m_max;
@@ -523,9 +514,22 @@ extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, con
         mp_set_error("null array");
         return MP_E_BADARG;
     }
-    F2cDev a{n_pts, m_max, s, l, pt_scn, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv, x, y};
+    F2cDev a{n_pts, m_max, s, l, pt_scn, 1, nullptr, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv, x, y};
     hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return c2f_launch_check("mp_f2c_batch");
+}
+
+// Frenet->Cartesian of pts_per_scn points per scene (scene-major), of which the
+// first n_valid[b] are converted and the rest set to 0.  Used by mp_plan_scenes.
+int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
+                int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
+                const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream)
+{
+    const int n_pts = B * pts_per_scn;
+    F2cDev a{n_pts, m_max, s, l, nullptr, pts_per_scn, n_valid, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv,
+             x, y};
+    hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_plan_scenes (frenet to cartesian)");
 }
 
 extern "C" int mp_curve_eval(int32_t B, const double *knots_t, const double *knots_x, const int32_t *n_knots,

@@ -1,0 +1,618 @@
+// Whole replan for B scenes behind one entry point (mp_plan_scenes), gfx950.
+//
+// Reference: Planning/Interface/planner_interface.py:54-68, 133-159 -- the chain
+// SLMap -> PathPlanner -> path_sampling -> STMap -> SpeedPlanner -> path_convert
+// that PlannerInterface.run_step walks for one scene.  Here every stage is a
+// kernel over all scenes and the stages hand their results to each other in
+// device memory (one arena, layout below), so the host enqueues a fixed list of
+// launches and never waits for a value: layer counts, obstacle counts, ST grid
+// widths and failure codes stay on the device as per-scene arrays.
+//
+// The heavy stages are the library's own entry points (mp_refline_tables,
+// mp_sl_plan, mp_curve_eval, mp_st_regions, mp_st_dp); this file adds the glue
+// the reference does in Python between them:
+//   plan_frontend_kernel  SLMap.create_frenet_map + add_obstacle (sl_map.py:33-112)
+//   plan_knots_kernel     knots of the path spline (path_planner.py:40-53)
+//   plan_stdims_kernel    STMap.__init__ grid width (st_map.py:13-22)
+//   plan_speed_kernel     knots of the speed spline (speed_planner.py:35-46)
+#pragma clang fp contract(off)
+#include "mp_device.h"
+#include "c2f_device.h"
+
+#include <string.h>
+
+extern void mp_set_error(const char *fmt, ...);
+int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
+                int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
+                const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream);
+int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
+                          const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
+                          const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
+                          const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
+                          int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
+                          int32_t *status, void *stream);
+
+// ---------------------------------------------------------------------------
+// Arena layout: X(name, C type, MP_F64 / MP_I32, dim0, dim1, dim2, dim3)
+// ---------------------------------------------------------------------------
+#define NOB(d) ((d).n_st_max + (d).n_dy_max * (d).n_frames > 0 ? (d).n_st_max + (d).n_dy_max * (d).n_frames : 1)
+#define ONE(n) ((n) > 0 ? (n) : 1)
+#define OPT(d, n) ((d).want_maps ? (n) : 0)
+#define PLAN_ARRAYS(X)                                                                       \
+    X(status, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
+    X(tab_x, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(tab_y, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(tab_s, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(tab_theta, double, MP_F64, d.B, d.m_max, 1, 1)                                         \
+    X(tab_kappa, double, MP_F64, d.B, d.m_max, 1, 1)                                         \
+    X(tab_m, int32_t, MP_I32, d.B, 1, 1, 1)                                                  \
+    X(origin, double, MP_F64, d.B, 4, 1, 1)                                                  \
+    X(rl_status, int32_t, MP_I32, d.B, 1, 1, 1)                                              \
+    X(inv_x, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(inv_s, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(inv_y, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
+    X(inv_theta, double, MP_F64, d.B, d.m_max, 1, 1)                                         \
+    X(n_inv, int32_t, MP_I32, d.B, 1, 1, 1)                                                  \
+    X(zeros, double, MP_F64, d.B, 2, 1, 1)                                                   \
+    X(ego_sl, double, MP_F64, d.B, 2, 1, 1)                                                  \
+    X(robot_vel, double, MP_F64, d.B, 1, 1, 1)                                               \
+    X(st_s, double, MP_F64, d.B, ONE(d.n_st_max), 1, 1)                                      \
+    X(st_l, double, MP_F64, d.B, ONE(d.n_st_max), 1, 1)                                      \
+    X(dy_s, double, MP_F64, d.B, ONE(d.n_dy_max), d.n_frames, 1)                             \
+    X(dy_l, double, MP_F64, d.B, ONE(d.n_dy_max), d.n_frames, 1)                             \
+    X(ob_s, double, MP_F64, d.B, NOB(d), 1, 1)                                               \
+    X(ob_l, double, MP_F64, d.B, NOB(d), 1, 1)                                               \
+    X(n_ob, int32_t, MP_I32, d.B, 1, 1, 1)                                                   \
+    X(ob_dist, double, MP_F64, d.B, 1, 1, 1)                                                 \
+    X(s_layers, double, MP_F64, d.B, d.n_s_max, 1, 1)                                        \
+    X(n_layers, int32_t, MP_I32, d.B, 1, 1, 1)                                               \
+    X(l_row, double, MP_F64, d.n_l, 1, 1, 1)                                                 \
+    X(path_idx, int32_t, MP_I32, d.B, d.n_s_max, 1, 1)                                       \
+    X(sl_status, int32_t, MP_I32, d.B, 1, 1, 1)                                              \
+    X(layers_done, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
+    X(best_cost, double, MP_F64, d.B, 1, 1, 1)                                               \
+    X(cost_map, double, MP_F64, OPT(d, d.B), d.n_s_max, d.n_l, 1)                            \
+    X(index_map, int32_t, MP_I32, OPT(d, d.B), d.n_s_max, d.n_l, 1)                          \
+    X(knots_t, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
+    X(knots_v, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
+    X(n_pk, int32_t, MP_I32, d.B, 1, 1, 1)                                                   \
+    X(path_s, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
+    X(path_l, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
+    X(n_path, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
+    X(path_status, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
+    X(st_n_s, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
+    X(st_down, double, MP_F64, d.B, d.n_t, d.r_max, 1)                                       \
+    X(st_up, double, MP_F64, d.B, d.n_t, d.r_max, 1)                                         \
+    X(st_n_reg, int32_t, MP_I32, d.B, d.n_t, 1, 1)                                           \
+    X(reg_status, int32_t, MP_I32, d.B, 1, 1, 1)                                             \
+    X(st_path_s_ind, int32_t, MP_I32, d.B, d.n_t, 1, 1)                                      \
+    X(st_path_len, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
+    X(st_cost, double, MP_F64, OPT(d, d.B), d.n_t, d.st_n_s_max, 1)                          \
+    X(st_pre, int32_t, MP_I32, OPT(d, d.B), d.n_t, d.st_n_s_max, 1)                          \
+    X(sp_t, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
+    X(sp_s, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
+    X(prof_t, double, MP_F64, d.B, d.q_max, 1, 1)                                            \
+    X(ss, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
+    X(vv, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
+    X(n_prof, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
+    X(prof_status, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
+    X(final_s, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
+    X(final_l, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
+    X(n_final, int32_t, MP_I32, d.B, 1, 1, 1)                                                \
+    X(final_status, int32_t, MP_I32, d.B, 1, 1, 1)                                           \
+    X(final_x, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
+    X(final_y, double, MP_F64, d.B, d.q_max, 1, 1)
+
+struct PlanPtrs {
+#define X(name, ctype, dt, d0, d1, d2, d3) ctype *name;
+    PLAN_ARRAYS(X)
+#undef X
+};
+
+struct ArrInfo {
+    const char *name;
+    int32_t dtype;
+    int64_t shape[4];
+    int64_t offset, bytes;
+};
+
+static int plan_array_table(const mp_plan_dims &d, ArrInfo *out, int64_t *total)
+{
+    int n = 0;
+    int64_t off = 0;
+#define X(nm, ctype, dt, d0, d1, d2, d3)                                              \
+    {                                                                                 \
+        ArrInfo &a = out[n++];                                                        \
+        a.name = #nm;                                                                 \
+        a.dtype = dt;                                                                 \
+        a.shape[0] = (d0); a.shape[1] = (d1); a.shape[2] = (d2); a.shape[3] = (d3);   \
+        a.bytes = a.shape[0] * a.shape[1] * a.shape[2] * a.shape[3] * (int64_t)sizeof(ctype); \
+        a.offset = off;                                                               \
+        off += (a.bytes + 255) & ~(int64_t)255;                                       \
+    }
+    PLAN_ARRAYS(X)
+#undef X
+    *total = off;
+    return n;
+}
+
+#define X(name, ctype, dt, d0, d1, d2, d3) +1
+static const int PLAN_N_ARRAYS = 0 PLAN_ARRAYS(X);
+#undef X
+
+static int check_dims(const mp_plan_dims *d)
+{
+    if (!d) { mp_set_error("null dims"); return MP_E_BADARG; }
+    if (d->B <= 0 || d->n_knots_max < 2 || d->n_st_max < 0 || d->n_dy_max < 0 || d->n_frames <= 0 ||
+        d->n_l <= 0 || d->m_max <= 0 || d->n_s_max <= 0 || d->p_max <= 0 || d->n_t < 2 || d->st_n_s_max <= 0 ||
+        d->r_max <= 0 || d->q_max <= 0) {
+        mp_set_error("mp_plan_dims: non-positive size");
+        return MP_E_BADARG;
+    }
+    if (d->n_t > d->n_frames && d->n_dy_max > 0) {
+        mp_set_error("mp_plan_dims: n_t time layers need at least n_t predicted frames per moving obstacle");
+        return MP_E_BADARG;
+    }
+    return MP_OK;
+}
+
+extern "C" int32_t mp_plan_array_count(void) { return PLAN_N_ARRAYS; }
+
+extern "C" int mp_plan_array_info(const mp_plan_dims *dims, int32_t i, const char **name, int32_t *dtype,
+                                  int64_t shape[4], int64_t *offset)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (i < 0 || i >= PLAN_N_ARRAYS || !name || !dtype || !shape || !offset) {
+        mp_set_error("mp_plan_array_info: bad index or null output");
+        return MP_E_BADARG;
+    }
+    ArrInfo tab[PLAN_N_ARRAYS];
+    int64_t total;
+    plan_array_table(*dims, tab, &total);
+    *name = tab[i].name;
+    *dtype = tab[i].dtype;
+    for (int k = 0; k < 4; ++k) shape[k] = tab[i].shape[k];
+    *offset = tab[i].offset;
+    return MP_OK;
+}
+
+extern "C" int64_t mp_plan_arena_bytes(const mp_plan_dims *dims)
+{
+    if (check_dims(dims)) return -1;
+    ArrInfo tab[PLAN_N_ARRAYS];
+    int64_t total;
+    plan_array_table(*dims, tab, &total);
+    return total;
+}
+
+extern "C" void mp_plan_default_params(mp_plan_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->l_width = 3.5;
+    p->save_width = 0.6;
+    p->layer_gap = 8.0;
+    p->max_map_len = 100.0;
+    p->d_x = 0.5;
+    p->path_dt = 0.5;
+    p->sl.d_s = 0.5;
+    p->sl.w_d = 0.5;
+    p->sl.no_path_cost = 1e4;
+    p->sl.early_exit = 1;
+    p->sl.mid_l = -1;
+    p->speed_lim = 25.0 * 5.0 / 18.0;
+    p->st_ds = 1.0;
+    p->st_dt = 0.5;
+    p->path_planner = 0;
+}
+
+// ---------------------------------------------------------------------------
+// glue kernels
+// ---------------------------------------------------------------------------
+struct FrontDev {
+    mp_scene_batch in;
+    mp_plan_dims d;
+    PlanPtrs o;
+    double l_width, layer_gap, max_map_len;
+    double l_start, l_stop, l_step; // lateral samples: np.linspace(l_start, l_stop, n_l)
+};
+
+// One workgroup per scene: ego state, lattice layers, every obstacle frame to
+// Frenet, lane filter and the obstacle list in the reference's order (statics,
+// then each moving obstacle's frames; sl_map.py:86-109).  The line's sample
+// table sits in LDS (x, y per sample).  Workgroup 0 also writes the lateral
+// sample row shared by all scenes.
+__global__ void plan_frontend_kernel(FrontDev a)
+{
+    extern __shared__ double smem[];
+    __shared__ int wave_cnt[16];
+    __shared__ int base_sh;
+    __shared__ double rmax_sh[16];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
+    const mp_plan_dims &d = a.d;
+    const int m_max = d.m_max;
+    if (b == 0) {
+        // np.linspace: i*step + start, the last sample set to stop (sl_map.py:74)
+        for (int i = tid; i < d.n_l; i += nt)
+            a.o.l_row[i] = (d.n_l > 1 && i == d.n_l - 1) ? a.l_stop : (double)i * a.l_step + a.l_start;
+    }
+    const int n_st = d.n_st_max > 0 ? min(max(a.in.n_st[b], 0), d.n_st_max) : 0;
+    const int n_dy = d.n_dy_max > 0 ? min(max(a.in.n_dy[b], 0), d.n_dy_max) : 0;
+    const int F = d.n_frames;
+    const int n_slot = d.n_st_max + d.n_dy_max * F;
+    const int ob_stride = NOB(d);
+    const int M = a.o.tab_m[b];
+    const bool line_ok = a.o.rl_status[b] == MP_RL_OK && M > 0;
+    const double end_s = a.o.origin[4 * b + 2];
+    if (!line_ok || end_s > a.max_map_len) {
+        if (tid == 0) {
+            a.o.status[b] = line_ok ? MP_PLAN_E_MAP_TOO_BIG : MP_PLAN_E_BAD_LINE;
+            a.o.n_layers[b] = 0;
+            a.o.n_ob[b] = 0;
+            a.o.ob_dist[b] = 0.0;
+            a.o.ego_sl[2 * b] = a.o.ego_sl[2 * b + 1] = a.o.robot_vel[b] = __builtin_nan("");
+        }
+        return;
+    }
+    double *tx = smem, *ty = smem + m_max;
+    const size_t tb = (size_t)b * m_max;
+    for (int k = tid; k < M; k += nt) {
+        tx[k] = a.o.tab_x[tb + k];
+        ty[k] = a.o.tab_y[tb + k];
+    }
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    const double *ts = a.o.tab_s + tb, *tth = a.o.tab_theta + tb;
+
+    if (tid == 0) {
+        // ego at the robot frame's origin (sl_map.py:38-42)
+        double s, l;
+        const int k = c2f_point(tx, ty, ts, tth, M, 0.0, 0.0, &s, &l);
+        a.o.ego_sl[2 * b] = s;
+        a.o.ego_sl[2 * b + 1] = l;
+        a.o.robot_vel[b] = c2f_s_dt(tth[k], a.o.tab_kappa[tb + k], l, a.in.ego_vel[2 * b], a.in.ego_vel[2 * b + 1]);
+    }
+    if (tid == MP_WAVE % nt) {
+        // layers every layer_gap, the line's end as the last one (sl_map.py:53-66)
+        double *lay = a.o.s_layers + (size_t)b * d.n_s_max;
+        double ss = a.layer_gap;
+        int n = 0;
+        bool full = false;
+        while (true) {
+            if (n >= d.n_s_max) { full = true; break; }
+            lay[n++] = ss;
+            ss += a.layer_gap;
+            if (ss + a.layer_gap / 2 >= end_s) {
+                if (n >= d.n_s_max) { full = true; break; }
+                lay[n++] = end_s;
+                break;
+            }
+        }
+        a.o.n_layers[b] = full ? 0 : n;
+        a.o.status[b] = full ? MP_PLAN_E_CAPACITY : MP_PLAN_OK;
+    }
+
+    double r_loc = 0.0;
+    for (int p0 = 0; p0 < n_slot; p0 += nt) {
+        const int p = p0 + tid;
+        bool keep = false;
+        double s = 0.0, l = 0.0;
+        if (p < n_slot) {
+            const bool is_st = p < d.n_st_max;
+            const int o = is_st ? p : (p - d.n_st_max) / F;
+            const bool used = is_st ? o < n_st : o < n_dy;
+            double rad = 0.0;
+            if (used) {
+                double x, y;
+                if (is_st) {
+                    const size_t q = (size_t)b * d.n_st_max + o;
+                    x = a.in.st_pos[2 * q];
+                    y = a.in.st_pos[2 * q + 1];
+                    rad = a.in.st_rad[q];
+                } else {
+                    const int f = (p - d.n_st_max) - o * F;
+                    const size_t q = (size_t)b * d.n_dy_max + o;
+                    x = a.in.dy_pos[2 * (q * F + f)];
+                    y = a.in.dy_pos[2 * (q * F + f) + 1];
+                    rad = a.in.dy_rad[q];
+                }
+                c2f_point(tx, ty, ts, tth, M, x, y, &s, &l);
+                keep = fabs(l) - rad < a.l_width; // check_in_line (sl_map.py:111-112)
+                if (keep) r_loc = rad > r_loc ? rad : r_loc;
+            }
+            if (is_st) {
+                a.o.st_s[(size_t)b * ONE(d.n_st_max) + o] = s;
+                a.o.st_l[(size_t)b * ONE(d.n_st_max) + o] = l;
+            } else {
+                const size_t q = (size_t)b * ONE(d.n_dy_max) * F + (p - d.n_st_max);
+                a.o.dy_s[q] = s;
+                a.o.dy_l[q] = l;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int pos = base_sh;
+        for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+        pos += __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) {
+            a.o.ob_s[(size_t)b * ob_stride + pos] = s;
+            a.o.ob_l[(size_t)b * ob_stride + pos] = l;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < nw; ++w) tot += wave_cnt[w];
+            base_sh += tot;
+        }
+        __syncthreads();
+    }
+    r_loc = -wave_min_f64(-r_loc);
+    if (lane == 0) rmax_sh[wave] = r_loc;
+    __syncthreads();
+    if (tid == 0) {
+        double r = rmax_sh[0];
+        for (int w = 1; w < nw; ++w) r = rmax_sh[w] > r ? rmax_sh[w] : r;
+        a.o.n_ob[b] = base_sh;
+        a.o.ob_dist[b] = r; // max radius of the kept entries (sl_map.py:94,106), 0 if none
+    }
+}
+
+struct GlueDev {
+    mp_plan_dims d;
+    PlanPtrs o;
+    double st_ds, st_dt;
+    int32_t mid_l, track;
+};
+
+// One thread per scene: outcome of the path search and the knots of the path
+// spline, [ego] + chosen nodes (path_planner.py:40-53; track_path_planner.py:25-35
+// takes the centre node of every layer).
+__global__ void plan_knots_kernel(GlueDev a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.d.B) return;
+    const int NS = a.d.n_s_max;
+    int st = a.o.status[b];
+    const int n = a.o.n_layers[b];
+    int32_t *pidx = a.o.path_idx + (size_t)b * NS;
+    if (st == MP_PLAN_OK) {
+        if (a.track) {
+            for (int s = 0; s < NS; ++s) pidx[s] = s < n ? a.mid_l : -1;
+            a.o.sl_status[b] = MP_SL_FOUND;
+            a.o.layers_done[b] = n;
+            a.o.best_cost[b] = __builtin_nan("");
+        }
+        const int sl = a.o.sl_status[b];
+        if (sl != MP_SL_FOUND) st = (sl == MP_SL_NOT_FOUND) ? MP_PLAN_NOT_FOUND : (sl < 0 ? sl : MP_PLAN_NOT_FOUND);
+    } else if (a.track) {
+        for (int s = 0; s < NS; ++s) pidx[s] = -1;
+        a.o.sl_status[b] = MP_SL_SKIPPED;
+        a.o.layers_done[b] = 0;
+        a.o.best_cost[b] = __builtin_nan("");
+    }
+    a.o.status[b] = st;
+    double *kt = a.o.knots_t + (size_t)b * (NS + 1), *kv = a.o.knots_v + (size_t)b * (NS + 1);
+    if (st != MP_PLAN_OK) {
+        a.o.n_pk[b] = 0;
+        return;
+    }
+    kt[0] = a.o.ego_sl[2 * b];
+    kv[0] = a.o.ego_sl[2 * b + 1];
+    const double *lay = a.o.s_layers + (size_t)b * NS;
+    for (int s = 0; s < n; ++s) {
+        kt[s + 1] = lay[s];
+        kv[s + 1] = a.o.l_row[pidx[s]];
+    }
+    a.o.n_pk[b] = n + 1;
+}
+
+// One thread per scene: ST grid width n_s = floor(s_end / ds) + 1 with s_end the
+// arc length of the last path sample (planner_interface.py:145, st_map.py:17).
+__global__ void plan_stdims_kernel(GlueDev a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.d.B) return;
+    int st = a.o.status[b];
+    int n_s = 0;
+    if (st == MP_PLAN_OK) {
+        const int P = a.o.n_path[b];
+        if (a.o.path_status[b] != MP_RL_OK || P <= 0) st = MP_PLAN_E_ST_CAPACITY;
+        else {
+            const double s_end = a.o.path_s[(size_t)b * a.d.p_max + P - 1];
+            const double q = floor(s_end / a.st_ds);
+            if (!(q >= 0.0) || q + 1.0 > (double)a.d.st_n_s_max) st = MP_PLAN_E_ST_CAPACITY;
+            else n_s = (int)q + 1;
+        }
+    }
+    if (st != MP_PLAN_OK) a.o.n_path[b] = 0; // later stages skip the scene
+    a.o.st_n_s[b] = n_s;
+    a.o.status[b] = st;
+}
+
+// One thread per scene: knots of the speed spline, t = 0, dt, 2dt, ... by
+// repeated addition and s = index * ds (speed_planner.py:35-46).
+__global__ void plan_speed_kernel(GlueDev a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.d.B) return;
+    int st = a.o.status[b];
+    const int n_t = a.d.n_t;
+    if (st == MP_PLAN_OK && a.o.reg_status[b] != MP_ST_OK) st = MP_PLAN_E_ST_CAPACITY;
+    a.o.status[b] = st;
+    if (st != MP_PLAN_OK) {
+        a.o.st_path_len[b] = 0;
+        return;
+    }
+    const int len = a.o.st_path_len[b];
+    double t = 0.0;
+    for (int i = 0; i < n_t; ++i) {
+        const int j = a.o.st_path_s_ind[(size_t)b * n_t + i];
+        a.o.sp_t[(size_t)b * n_t + i] = t;
+        a.o.sp_s[(size_t)b * n_t + i] = i < len ? (double)j * a.st_ds : 0.0;
+        t += a.st_dt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+static int pipe_launch_check(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mp_set_error("%s: %s", what, hipGetErrorString(e));
+        return MP_E_LAUNCH;
+    }
+    return MP_OK;
+}
+
+extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                              void *arena, int64_t arena_bytes, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!scenes || !params || !arena) { mp_set_error("null scenes/params/arena"); return MP_E_BADARG; }
+    const mp_plan_dims d = *dims;
+    const mp_scene_batch &in = *scenes;
+    if (!in.knots_x || !in.knots_y || !in.n_knots || !in.line_vec || !in.ego_vel ||
+        (d.n_st_max > 0 && (!in.st_pos || !in.st_rad || !in.n_st)) ||
+        (d.n_dy_max > 0 && (!in.dy_pos || !in.dy_rad || !in.n_dy))) {
+        mp_set_error("mp_scene_batch: null array");
+        return MP_E_BADARG;
+    }
+    if (((uintptr_t)arena & 255) != 0) { mp_set_error("arena must be 256-byte aligned"); return MP_E_BADARG; }
+    ArrInfo tab[PLAN_N_ARRAYS];
+    int64_t total;
+    plan_array_table(d, tab, &total);
+    if (arena_bytes < total) {
+        mp_set_error("arena too small: %lld bytes needed", (long long)total);
+        return MP_E_BADARG;
+    }
+    if (d.n_l > 256 || (size_t)d.n_s_max * d.n_l > 65536 || d.n_t > 64 || d.st_n_s_max > 1024 || d.r_max > 256 ||
+        d.m_max > 4096 || d.p_max > 4096 || d.q_max > 4096 || d.n_s_max + 1 > 128) {
+        mp_set_error("mp_plan_scenes: a size exceeds what the kernels support");
+        return MP_E_UNSUPPORTED;
+    }
+    PlanPtrs o;
+    {
+        int i = 0;
+        char *base = (char *)arena;
+#define X(name, ctype, dt, d0, d1, d2, d3) \
+    o.name = tab[i].bytes ? (ctype *)(base + tab[i].offset) : nullptr; \
+    ++i;
+        PLAN_ARRAYS(X)
+#undef X
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const mp_plan_params &p = *params;
+    const int B = d.B;
+    const int mid_l = p.sl.mid_l >= 0 ? p.sl.mid_l : (int)((d.n_l - 1) / 2);
+    if (mid_l >= d.n_l) { mp_set_error("mid_l out of range"); return MP_E_BADARG; }
+
+    // result rows whose tails nobody writes start from zero
+    struct { void *p; int64_t n; } clr[] = {
+        {o.zeros, (int64_t)B * 2 * 8}, // the ego position (0, 0) and the path spline's end slope
+        {o.path_s, (int64_t)B * d.p_max * 8}, {o.path_l, (int64_t)B * d.p_max * 8},
+        {o.prof_t, (int64_t)B * d.q_max * 8}, {o.ss, (int64_t)B * d.q_max * 8}, {o.vv, (int64_t)B * d.q_max * 8},
+        {o.final_s, (int64_t)B * d.q_max * 8}, {o.final_l, (int64_t)B * d.q_max * 8},
+        {o.sp_t, (int64_t)B * d.n_t * 8}, {o.sp_s, (int64_t)B * d.n_t * 8},
+        {o.knots_t, (int64_t)B * (d.n_s_max + 1) * 8}, {o.knots_v, (int64_t)B * (d.n_s_max + 1) * 8},
+        {o.s_layers, (int64_t)B * d.n_s_max * 8},
+    };
+    for (auto &c : clr) (void)hipMemsetAsync(c.p, 0, (size_t)c.n, st);
+
+    // 1. Frenet frame of every scene, the ego at the robot frame's origin
+    rc = mp_refline_tables(B, in.knots_x, in.knots_y, in.n_knots, d.n_knots_max, in.line_vec, o.zeros, p.d_x,
+                           d.m_max, o.tab_x, o.tab_y, o.tab_s, o.tab_theta, o.tab_kappa, o.tab_m, o.origin,
+                           o.rl_status, o.inv_x, o.inv_s, o.inv_y, o.inv_theta, o.n_inv, stream);
+    if (rc) return rc;
+
+    // 2. ego state, layers, obstacle frames to Frenet, obstacle list
+    {
+        FrontDev f;
+        f.in = in;
+        f.d = d;
+        f.o = o;
+        f.l_width = p.l_width;
+        f.layer_gap = p.layer_gap;
+        f.max_map_len = p.max_map_len;
+        f.l_start = 0.0 - (p.l_width - p.save_width) / 2.0; // sl_map.py:71-72
+        f.l_stop = 0.0 + (p.l_width - p.save_width) / 2.0;
+        f.l_step = d.n_l > 1 ? (f.l_stop - f.l_start) / (double)(d.n_l - 1) : 0.0;
+        const size_t lds = (size_t)2 * d.m_max * sizeof(double);
+        if (lds > 64 * 1024) { mp_set_error("m_max too large"); return MP_E_UNSUPPORTED; }
+        const int n_slot = d.n_st_max + d.n_dy_max * d.n_frames;
+        const int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);
+        hipLaunchKernelGGL(plan_frontend_kernel, dim3(B), dim3(threads), lds, st, f);
+        rc = pipe_launch_check("mp_plan_scenes (front end)");
+        if (rc) return rc;
+    }
+
+    GlueDev g;
+    g.d = d;
+    g.o = o;
+    g.st_ds = p.st_ds;
+    g.st_dt = p.st_dt;
+    g.mid_l = mid_l;
+    g.track = p.path_planner == 1;
+    const dim3 per_scene((B + 127) / 128), blk(128);
+
+    // 3. path search over the lattice
+    if (!g.track) {
+        mp_sl_batch sb;
+        sb.B = B;
+        sb.n_s = d.n_s_max;
+        sb.n_l = d.n_l;
+        sb.ob_stride = NOB(d);
+        sb.s_layers = o.s_layers;
+        sb.l_map = o.l_row;
+        sb.l_bstride = 0; // one lateral row for every scene and layer
+        sb.l_rstride = 0;
+        sb.ego_sl = o.ego_sl;
+        sb.ob_s = o.ob_s;
+        sb.ob_l = o.ob_l;
+        sb.n_ob = o.n_ob;
+        sb.ob_dist = o.ob_dist;
+        sb.n_layers = o.n_layers;
+        mp_sl_params sp = p.sl;
+        sp.mid_l = mid_l;
+        rc = mp_sl_plan(&sb, &sp, o.cost_map, o.index_map, o.path_idx, o.sl_status, o.layers_done, o.best_cost,
+                        stream);
+        if (rc) return rc;
+    }
+    // 4. knots of the path spline, 5. the path every path_dt
+    hipLaunchKernelGGL(plan_knots_kernel, per_scene, blk, 0, st, g);
+    rc = pipe_launch_check("mp_plan_scenes (path knots)");
+    if (rc) return rc;
+    const double *zero_vec = o.zeros; // end slope 0.0 (path_planner.py:53)
+    rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 0, nullptr, nullptr,
+                       d.p_max, o.path_s, o.path_l, nullptr, o.n_path, o.path_status, stream);
+    if (rc) return rc;
+
+    // 6. ST grid width, 7. blocked intervals, 8. speed search
+    hipLaunchKernelGGL(plan_stdims_kernel, per_scene, blk, 0, st, g);
+    rc = pipe_launch_check("mp_plan_scenes (ST grid)");
+    if (rc) return rc;
+    rc = mp_st_regions_strided(B, d.n_t, o.path_s, o.path_l, o.n_path, d.p_max, o.st_s, o.st_l, in.st_rad, in.n_st,
+                               d.n_st_max, o.dy_s, o.dy_l, in.dy_rad, in.n_dy, d.n_dy_max, d.n_frames, d.r_max,
+                               o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream);
+    if (rc) return rc;
+    rc = mp_st_dp(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
+                  p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len, stream);
+    if (rc) return rc;
+
+    // 9. speed profile every dt/5, 10. path points at its arc lengths, 11. back to the robot frame
+    hipLaunchKernelGGL(plan_speed_kernel, per_scene, blk, 0, st, g);
+    rc = pipe_launch_check("mp_plan_scenes (speed knots)");
+    if (rc) return rc;
+    const double curve_dt = p.st_dt * 1.0 / 5; // speed_planner.py:22
+    rc = mp_curve_eval(B, o.sp_t, o.sp_s, o.st_path_len, d.n_t, o.robot_vel, curve_dt, 1, nullptr, nullptr, d.q_max,
+                       o.prof_t, o.ss, o.vv, o.n_prof, o.prof_status, stream);
+    if (rc) return rc;
+    rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 2, o.ss, o.n_prof,
+                       d.q_max, o.final_s, o.final_l, nullptr, o.n_final, o.final_status, stream);
+    if (rc) return rc;
+    return mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
+                       o.inv_theta, o.n_inv, o.final_x, o.final_y, stream);
+}

@@ -267,6 +267,11 @@ __global__ void st_dp_kernel(StDev a)
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int N = a.n_s_max, n_t = a.n_t, R_max = a.r_max;
     const int n_s = a.n_s[b];
+    if (n_s <= 0 || n_s > N) { // no grid for this scenario: no path
+        for (int i = tid; i < n_t; i += nt) a.path_s_ind[(size_t)b * n_t + i] = -1;
+        if (tid == 0) a.path_len[b] = 0;
+        return;
+    }
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     StSh sh;
     sh.cost_prev = smem;
@@ -448,6 +453,7 @@ __device__ __forceinline__ double sqrt_threshold(double r)
 
 struct RegDev {
     int32_t n_t, p_max, n_st_max, n_dy_max, r_max;
+    int32_t dy_fstride; // frames stored per moving obstacle in dy_s / dy_l (>= n_t)
     const double *path_s, *path_l;
     const int32_t *n_path;
     const double *st_s, *st_l, *st_r;
@@ -493,8 +499,8 @@ __global__ void st_regions_kernel(RegDev a)
                     rad = a.st_r[(size_t)b * a.n_st_max + o];
                 } else {
                     const size_t q = (size_t)b * a.n_dy_max + (o - n_st);
-                    ox = a.dy_s[q * a.n_t + i];
-                    oy = a.dy_l[q * a.n_t + i];
+                    ox = a.dy_s[q * a.dy_fstride + i];
+                    oy = a.dy_l[q * a.dy_fstride + i];
                     rad = a.dy_r[q];
                 }
                 const double thr = sqrt_threshold(rad);
@@ -576,6 +582,14 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     return st_launch_check("mp_st_dp");
 }
 
+// mp_st_regions with dy_s / dy_l rows of dy_fstride >= n_t frames per obstacle.
+int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
+                          const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
+                          const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
+                          const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
+                          int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
+                          int32_t *status, void *stream);
+
 extern "C" int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
                              const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
                              const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
@@ -583,6 +597,18 @@ extern "C" int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const
                              int32_t r_max, double *s_down, double *s_up, int32_t *n_reg, int32_t *status,
                              void *stream)
 {
+    return mp_st_regions_strided(B, n_t, path_s, path_l, n_path, p_max, st_s, st_l, st_r, n_st, n_st_max, dy_s,
+                                 dy_l, dy_r, n_dy, n_dy_max, n_t, r_max, s_down, s_up, n_reg, status, stream);
+}
+
+int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
+                          const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
+                          const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
+                          const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
+                          int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
+                          int32_t *status, void *stream)
+{
+    if (dy_fstride < n_t) { mp_set_error("fewer stored frames than time layers"); return MP_E_BADARG; }
     if (B <= 0 || n_t <= 0 || p_max <= 0 || r_max <= 0 || n_st_max < 0 || n_dy_max < 0) {
         mp_set_error("bad sizes");
         return MP_E_BADARG;
@@ -595,7 +621,7 @@ extern "C" int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const
     }
     size_t lds = (size_t)2 * p_max * sizeof(double);
     if (lds > 128 * 1024) { mp_set_error("mp_st_regions: p_max too large"); return MP_E_UNSUPPORTED; }
-    RegDev a{n_t, p_max, n_st_max, n_dy_max, r_max, path_s, path_l, n_path, st_s, st_l, st_r,
+    RegDev a{n_t, p_max, n_st_max, n_dy_max, r_max, dy_fstride, path_s, path_l, n_path, st_s, st_l, st_r,
              n_st_max > 0 ? n_st : nullptr, dy_s, dy_l, dy_r, n_dy_max > 0 ? n_dy : nullptr,
              s_down, s_up, n_reg, status};
     int n_ob = n_st_max + n_dy_max;

@@ -90,12 +90,11 @@ def test_planner_interface_golden(planner):
         close(np.array(speed_buff), want_v, rtol=1e-9, atol=1e-9)
     # the intermediate Frenet path and the robot-frame path as well
     r = pi.result
-    found = list(r["found_ids"].cpu().numpy())
     for b, c in enumerate(cases):
         p = c + "_" + planner + "_"
         if not bool(g[p + "found"]):
             continue
-        k = found.index(b)
+        k = b
         n = int(r["n_prof"][k])
         close(r["ss"][k, :n].cpu().numpy(), g[p + "ss"], rtol=1e-9, atol=1e-9)
         close(np.stack([r["final_s"][k, :n].cpu().numpy(), r["final_l"][k, :n].cpu().numpy()], 1), g[p + "path_sl"],

@@ -50,14 +50,14 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     sc = make_scenes(B)
     dev = {k: torch.as_tensor(v).cuda() for k, v in sc.items()}
-    r = pl.plan_batch(n_l=n_l, **dev)
+    r = pl.plan_batch(n_l=n_l, m_max=232, **dev)
     torch.cuda.synchronize()
     st = r["status"].cpu().numpy()
     print("B=%d n_l=%d: found %.3f, not found %.3f, other %.3f" %
           (B, n_l, (st == 1).mean(), (st == 0).mean(), ((st != 0) & (st != 1)).mean()))
     t0 = time.perf_counter()
     for _ in range(reps):
-        r = pl.plan_batch(n_l=n_l, **dev)
+        r = pl.plan_batch(n_l=n_l, m_max=232, arena=r["arena"], **dev)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print("plan_batch: %.3f ms per call, %.0f plans/s" % (dt * 1e3, B / dt))
