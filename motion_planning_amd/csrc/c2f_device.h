@@ -5,19 +5,35 @@
 #pragma once
 #include "mp_device.h"
 
-// Curve.projection + cal_dist_arr: the first minimum of the distances to the M
-// samples (tx, ty); then the sign of the lateral offset from the heading at that
+// Curve.projection + cal_dist_arr (Utils/tool.py:62-72): the first minimum of the
+// distances sqrt(dx^2 + dy^2) to the M samples (tx, ty), found without a square
+// root per sample; then the sign of the lateral offset from the heading at that
 // sample and the arc length from the table.  Returns the sample index.
 __device__ __forceinline__ int c2f_point(const double *tx, const double *ty, const double *ts,
                                          const double *tth, int M, double x, double y, double *s_out,
                                          double *l_out)
 {
-    double best = MP_INF;
+    // sqrt is monotone, so the smallest distance is the root of the smallest squared
+    // distance; the first sample that reaches it is the first one whose squared
+    // distance does not exceed the largest double with that same rounded root.
+    double m2 = MP_INF;
     int k = 0;
     for (int i = 0; i < M; ++i) {
         const double dx = tx[i] - x, dy = ty[i] - y;
-        const double d = __dsqrt_rn(dx * dx + dy * dy);
-        if (d < best) { best = d; k = i; }
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < m2) { m2 = d2; k = i; }
+    }
+    const double best = __dsqrt_rn(m2);
+    double top = m2;
+    for (int it = 0; it < 8; ++it) {
+        const double nx = nextafter(top, MP_INF);
+        if (__dsqrt_rn(nx) == best) top = nx; else break;
+    }
+    if (top > m2) {
+        for (int i = 0; i < k; ++i) {
+            const double dx = tx[i] - x, dy = ty[i] - y;
+            if (dx * dx + dy * dy <= top) { k = i; break; }
+        }
     }
     const double th = tth[k];
     const double dx = x - tx[k], dy = y - ty[k];

@@ -540,6 +540,141 @@ __global__ void st_regions_kernel(RegDev a)
     if (tid == 0) a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
 }
 
+
+// Scan of the path for one obstacle: arc length of the first and of the last
+// path point closer than the radius (st_map.py:48-60).
+__device__ __forceinline__ bool scan_path(const double *ps, const double *pl, int P, double ox, double oy,
+                                          double thr, double *dn_out, double *u_out)
+{
+    bool hit = false;
+    double dn = 0.0, u = 0.0;
+    for (int k = 0; k < P; ++k) {
+        double dx = __dsub_rn(ox, ps[k]), dy = __dsub_rn(oy, pl[k]);
+        double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+        if (d2 < thr) {
+            if (!hit) { dn = ps[k]; hit = true; }
+            u = ps[k];
+        }
+    }
+    *dn_out = dn;
+    *u_out = u;
+    return hit;
+}
+
+// Same result as st_regions_kernel with the scans done once.  A static obstacle
+// blocks the same interval at every time layer, so it is scanned once instead of
+// n_t times; (obstacle, layer) items whose circle cannot reach the path's
+// bounding box are dropped before any scan; the surviving items are gathered in
+// a work list so that every lane scans; the per-layer lists are then written in
+// the reference's order from the stored results.  Items: q < n_st the statics,
+// then q = n_st + o*n_t + i for frame i of moving obstacle o.
+// Dynamic LDS: ps[p_max] pl[p_max] | res_dn[n_items_max] res_u[n_items_max] |
+//   work[n_items_max] u16 | flag[n_items_max] u8
+__global__ void st_regions_once_kernel(RegDev a, int n_items_max)
+{
+    extern __shared__ double smem[];
+    __shared__ int wave_cnt[16];
+    __shared__ int base_sh, n_work_sh;
+    __shared__ double box_sh[4][16];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
+    const int P = a.n_path[b], n_st = a.n_st ? a.n_st[b] : 0, n_dy = a.n_dy ? a.n_dy[b] : 0;
+    const int n_t = a.n_t;
+    double *ps = smem, *pl = smem + a.p_max;
+    double *res_dn = pl + a.p_max, *res_u = res_dn + n_items_max;
+    unsigned short *work = (unsigned short *)(res_u + n_items_max);
+    unsigned char *flag = (unsigned char *)(work + n_items_max + (n_items_max & 1));
+    // path into LDS and its bounding box
+    double s_lo = MP_INF, s_hi = -MP_INF, l_lo = MP_INF, l_hi = -MP_INF;
+    for (int k = tid; k < P; k += nt) {
+        const double s = a.path_s[(size_t)b * a.p_max + k], l = a.path_l[(size_t)b * a.p_max + k];
+        ps[k] = s;
+        pl[k] = l;
+        s_lo = s < s_lo ? s : s_lo; s_hi = s > s_hi ? s : s_hi;
+        l_lo = l < l_lo ? l : l_lo; l_hi = l > l_hi ? l : l_hi;
+    }
+    s_lo = wave_min_f64(s_lo); s_hi = -wave_min_f64(-s_hi);
+    l_lo = wave_min_f64(l_lo); l_hi = -wave_min_f64(-l_hi);
+    if (lane == 0) { box_sh[0][wave] = s_lo; box_sh[1][wave] = s_hi; box_sh[2][wave] = l_lo; box_sh[3][wave] = l_hi; }
+    if (tid == 0) n_work_sh = 0;
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        s_lo = box_sh[0][w] < s_lo ? box_sh[0][w] : s_lo; s_hi = box_sh[1][w] > s_hi ? box_sh[1][w] : s_hi;
+        l_lo = box_sh[2][w] < l_lo ? box_sh[2][w] : l_lo; l_hi = box_sh[3][w] > l_hi ? box_sh[3][w] : l_hi;
+    }
+    const int n_items = n_st + n_dy * n_t;
+    auto item = [&](int q, double *ox, double *oy, double *rad) {
+        if (q < n_st) {
+            *ox = a.st_s[(size_t)b * a.n_st_max + q];
+            *oy = a.st_l[(size_t)b * a.n_st_max + q];
+            *rad = a.st_r[(size_t)b * a.n_st_max + q];
+        } else {
+            const int o = (q - n_st) / n_t, i = (q - n_st) - o * n_t;
+            const size_t g = (size_t)b * a.n_dy_max + o;
+            *ox = a.dy_s[g * a.dy_fstride + i];
+            *oy = a.dy_l[g * a.dy_fstride + i];
+            *rad = a.dy_r[g];
+        }
+    };
+    // items that can reach the path's bounding box (margin: the radius plus slack
+    // well above the rounding of the distance test)
+    for (int q = tid; q < n_items; q += nt) {
+        double ox, oy, rad;
+        item(q, &ox, &oy, &rad);
+        flag[q] = 0;
+        const double m = fabs(rad) * (1.0 + 1e-9) + 1e-9;
+        const bool can = P > 0 && ox >= s_lo - m && ox <= s_hi + m && oy >= l_lo - m && oy <= l_hi + m;
+        if (can) work[atomicAdd(&n_work_sh, 1)] = (unsigned short)q;
+    }
+    __syncthreads();
+    const int n_work = n_work_sh;
+    for (int w = tid; w < n_work; w += nt) {
+        const int q = work[w];
+        double ox, oy, rad, dn, u;
+        item(q, &ox, &oy, &rad);
+        const bool hit = scan_path(ps, pl, P, ox, oy, sqrt_threshold(rad), &dn, &u);
+        flag[q] = hit;
+        res_dn[q] = dn;
+        res_u[q] = u;
+    }
+    __syncthreads();
+    // per-layer lists in the reference's order: statics, then moving obstacles
+    int overflow = 0;
+    const int n_ob = n_st + n_dy;
+    for (int i = 0; i < n_t; ++i) {
+        if (tid == 0) base_sh = 0;
+        __syncthreads();
+        for (int o0 = 0; o0 < n_ob; o0 += nt) {
+            const int o = o0 + tid;
+            const int q = o < n_st ? o : n_st + (o - n_st) * n_t + i;
+            const bool hit = o < n_ob && flag[q];
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int pos = base_sh;
+            for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+            pos += __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit) {
+                if (pos < a.r_max) {
+                    a.s_down[((size_t)b * n_t + i) * a.r_max + pos] = res_dn[q];
+                    a.s_up[((size_t)b * n_t + i) * a.r_max + pos] = res_u[q];
+                } else overflow = 1;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int w = 0; w < nw; ++w) tot += wave_cnt[w];
+                base_sh += tot;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) a.n_reg[(size_t)b * n_t + i] = min(base_sh, a.r_max);
+        __syncthreads();
+    }
+    overflow = __syncthreads_or(overflow);
+    if (tid == 0) a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
+}
+
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
@@ -626,6 +761,16 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
              s_down, s_up, n_reg, status};
     int n_ob = n_st_max + n_dy_max;
     int threads = n_ob <= 64 ? 64 : (n_ob <= 128 ? 128 : 256);
+    // every scan once, results kept in LDS, when they fit (MP_ST_REGIONS_ONCE=0: per-layer scans)
+    const int n_items_max = n_st_max + n_dy_max * n_t;
+    const size_t lds_once = lds + (size_t)n_items_max * 19 + 16;
+    const char *once_env = getenv("MP_ST_REGIONS_ONCE");
+    if (n_items_max <= 65535 && lds_once <= 64 * 1024 && !(once_env && atoi(once_env) == 0)) {
+        threads = n_items_max <= 64 ? 64 : (n_items_max <= 128 ? 128 : 256);
+        hipLaunchKernelGGL(st_regions_once_kernel, dim3(B), dim3(threads), lds_once, (hipStream_t)stream, a,
+                           n_items_max);
+        return st_launch_check("mp_st_regions");
+    }
     hipLaunchKernelGGL(st_regions_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return st_launch_check("mp_st_regions");
 }

@@ -202,12 +202,18 @@ def test_st_regions_pipeline_goldens():
             assert np.array_equal(up[b, i, :want_n[i]].cpu().numpy(), g[c + "_st_up"][i, :want_n[i]])
 
 
-def test_st_regions_random_vs_oracle(oracle):
+@pytest.mark.parametrize("once", [True, False], ids=["scan_once", "scan_per_layer"])
+@pytest.mark.parametrize("sizes", [(300, 40, 64), (3, 2, 4), (64, 0, 64), (0, 9, 8)], ids=str)
+def test_st_regions_random_vs_oracle(oracle, sizes, once, monkeypatch):
+    """Both kernels behind mp_st_regions: every (obstacle, layer) scanned once with the
+    results kept on chip, and the plain scan per layer used when they do not fit."""
     import torch
     from motion_planning_amd import batch as mb
+    if not once:
+        monkeypatch.setenv("MP_ST_REGIONS_ONCE", "0")
     rng = np.random.default_rng(77)
     B, n_t, p_max = 12, 11, 150
-    n_st_max, n_dy_max, r_max = 300, 40, 64
+    n_st_max, n_dy_max, r_max = sizes
     npath = rng.integers(1, p_max + 1, B).astype(np.int32)
     ps = np.cumsum(np.full((B, p_max), 0.5), axis=1) - 0.5
     pl = 0.8 * np.sin(ps / 7.0 + rng.uniform(0, 3, (B, 1)))
@@ -215,6 +221,7 @@ def test_st_regions_random_vs_oracle(oracle):
     n_st[0], n_st[1] = 0, n_st_max
     n_dy = rng.integers(0, n_dy_max + 1, B).astype(np.int32)
     n_dy[0] = 0
+    npath[2] = 1
     st_s, st_l = rng.uniform(-5, 80, (B, n_st_max)), rng.uniform(-6, 6, (B, n_st_max))
     st_r = rng.uniform(0.2, 1.5, (B, n_st_max))
     dy_s = rng.uniform(-5, 80, (B, n_dy_max, 1)) + rng.uniform(-3, 3, (B, n_dy_max, 1)) * np.arange(n_t) * 0.5
