@@ -61,6 +61,161 @@ def make_scenarios(first_id, B):
                 n_reg=np.full((B, ST_N_T), ST_R, np.int32), st_n_s=np.full(B, ST_N_S, np.int32))
 
 
+def make_scenes(B, n_st=192, n_dy=64, seed=5):
+    """Full-pipeline workload: robot-frame scenes on curved reference lines y = c x^2 with
+    16..21 knots every 4.5 m (map length <= 100 m), ego speed (U(3,8), U(-.5,.5)), 192
+    static and 64 moving obstacles (radius 0.8, 11 predicted frames) spread along the
+    line, most of them beside the road so that a share of the scenes keeps a free path."""
+    rng = np.random.default_rng(seed)
+    nk_max = 21
+    kx, ky = np.zeros((B, nk_max)), np.zeros((B, nk_max))
+    nk = rng.integers(16, nk_max + 1, B).astype(np.int32)
+    c = rng.uniform(-0.006, 0.006, B)
+    for b in range(B):
+        xs = -2.0 + 4.5 * np.arange(nk[b])
+        kx[b, :nk[b]], ky[b, :nk[b]] = xs, c[b] * xs * xs
+    x_end = -2.0 + 4.5 * (nk - 1)
+    ego_vel = np.stack([rng.uniform(3, 8, B), rng.uniform(-0.5, 0.5, B)], 1)
+    st_x = rng.uniform(0, 1, (B, n_st)) * x_end[:, None]
+    off = rng.uniform(2.0, 14.0, (B, n_st)) * rng.choice([-1.0, 1.0], (B, n_st))
+    st_pos = np.stack([st_x, c[:, None] * st_x * st_x + off], 2)
+    dy_x = rng.uniform(0, 1, (B, n_dy)) * x_end[:, None]
+    dy0 = np.stack([dy_x, c[:, None] * dy_x * dy_x + rng.uniform(2.5, 12.0, (B, n_dy)) *
+                    rng.choice([-1.0, 1.0], (B, n_dy))], 2)
+    vel = np.stack([rng.uniform(-3, 3, (B, n_dy)), rng.uniform(-0.3, 0.3, (B, n_dy))], 2)
+    frames = [dy0]
+    for _ in range(10):
+        frames.append(frames[-1] + vel * 0.5)
+    dy_pos = np.stack(frames, 2)
+    return dict(knots_x=kx, knots_y=ky, n_knots=nk, ego_vel=ego_vel, st_pos=st_pos,
+                st_rad=np.full((B, n_st), 0.8), n_st=np.full(B, n_st, np.int32), dy_pos=dy_pos,
+                dy_rad=np.full((B, n_dy), 0.8), n_dy=np.full(B, n_dy, np.int32))
+
+
+def cpu_pipeline(sc, n_sample, threads):
+    """The CPU oracle's whole replan (Frenet map, SL DP, path sampling, ST map, ST DP,
+    speed profile, conversion back) on the first n_sample scenes, `threads` at a time."""
+    import contextlib
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+
+    def one(b):
+        nk = int(sc["n_knots"][b])
+        st = [(p, r) for p, r in zip(sc["st_pos"][b], sc["st_rad"][b])]
+        dy = [(fr, r) for fr, r in zip(sc["dy_pos"][b], sc["dy_rad"][b])]
+        try:
+            sl = orc.SLMap(sc["knots_x"][b, :nk], sc["knots_y"][b, :nk], 0.0, sc["ego_vel"][b], st, dy)
+        except ValueError:
+            return 0
+        found, curve, _ = orc.sl_plan(sl)
+        if not found:
+            return 0
+        pb = sl.path_sampling(curve)
+        n_s, n_t = orc.st_dims(pb[-1][0])
+        down, up, n_reg = orc.st_add_obstacle(n_t, pb, sl.st_ob_traj, sl.dy_ob_traj)
+        sr = orc.st_find_speed(n_t, n_s, down, up, n_reg, sl.robot_vel, SPEED_LIM)
+        ss, vv = orc.speed_profile(sr["path_s_ind"], sl.robot_vel)
+        sl.path_convert(sl.path_sampling(curve, ss))
+        return 1
+
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()), ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(n_sample)))
+    dt = time.perf_counter() - t0
+    return n_sample / dt, dt
+
+
+def bench_pipeline(args, world, rank, backend):
+    """--workload pipeline: one step = one mp_plan_scenes call over B scenes resident in
+    HBM (every stage of the replan) and, with more than one GPU, the result gather."""
+    import torch
+    import torch.distributed as dist
+    from motion_planning_amd import batch as mb, dist as mdist, pipeline as pl
+
+    B = args.scenarios
+    sc = make_scenes(B, seed=5 + rank)
+    dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
+    dev["line_vec"] = torch.zeros(B, dtype=torch.float64, device="cuda")
+    params = pl.default_params()
+    dims = pl.plan_dims(B, sc["knots_x"].shape[1], sc["st_pos"].shape[1], sc["dy_pos"].shape[1], n_l=5, m_max=200,
+                        params=params)
+    arena = pl.PlanArena(dims)
+    a = arena.arrays
+    row = mdist.record_width(dims.n_s_max, dims.n_t)
+    packed = torch.empty((B, row), dtype=torch.int32, device="cuda")
+    gdev = "cuda" if backend == "nccl" else "cpu"
+    gathered = torch.empty((world * B, row), dtype=torch.int32, device=gdev) if world > 1 else None
+
+    def step():
+        pl.plan_scenes(dev, dims, params, arena)
+        if world > 1:
+            mdist.pack_results(a["path_idx"], a["sl_status"], a["layers_done"], a["best_cost"], a["st_path_s_ind"],
+                               a["st_path_len"], out=packed)
+            mdist.gather_results_same_size(packed if backend == "nccl" else packed.cpu(), gathered)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    status = a["status"].cpu().numpy()
+    assert set(np.unique(status)) <= {1, 0, -4}, "unexpected scene status %s" % np.unique(status)
+    n_prof = a["n_prof"].cpu().numpy()
+    assert (n_prof[status == 1] >= 2).all()
+    if rank != 0:
+        return
+    n_pts = B * (sc["st_pos"].shape[1] + sc["dy_pos"].shape[1] * 11 + 1)
+    bytes_in = sum(v.nbytes for v in sc.values())
+    bytes_out = B * (8 * 3 * dims.q_max + 4 * 2)   # final x, y, speed profile, status, count
+    ms = 1e3 * elapsed / args.steps
+    res = {
+        "metric": "full replan plans/sec (Cartesian->Frenet + SL path DP + ST speed DP + speed profile + path in "
+                  "the robot frame)",
+        "value": world * B * args.steps / elapsed, "unit": "plans/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "full pipeline: %d scenes/GPU, curved reference lines of 16-21 knots, 192 static + "
+                               "64 moving obstacles (897 points to Frenet per scene), default lattice (5 lanes, "
+                               "layers every 8 m), default ST grid; one mp_plan_scenes call per step" % B,
+                   "scenarios_per_gpu": B, "n_l": 5, "n_st": 192, "n_dy": 64,
+                   "parallelism": "scenario-sharded x%d" % world},
+        "c2f_points_per_sec": world * n_pts * args.steps / elapsed,
+        "status_fractions": {"planned": float((status == 1).mean()), "no_path": float((status == 0).mean()),
+                             "map_longer_than_100m": float((status == -4).mean())},
+        "roofline": {"bound": "hbm", "kernel": "whole chain (13 kernels, see profiles/ for the split)",
+                     "achieved": (bytes_in + bytes_out) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (bytes_in + bytes_out) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_in + bytes_out,
+                     "note": "algorithmic bytes = the scenes in and the plans out; every stage in between works "
+                             "from LDS-resident tables, so the chain is bound by instruction issue and latency, "
+                             "not by HBM"},
+    }
+    if args.cpu_sample > 0:
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        n = min(args.cpu_sample, B)
+        v, dt = cpu_pipeline(sc, n, threads)
+        res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
+                               "sample": "first %d scenes of the same batch, whole replan, C oracle driven from "
+                                         "Python, %d threads, %.1f s" % (n, threads, dt)}
+    print(json.dumps(res))
+
+
 def load_pmc():
     """Per-kernel counter means (per launch) from the last committed rocprofv3 --pmc passes of this
     same command; bench.py cannot collect them itself."""
@@ -106,6 +261,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenarios", type=int, default=4096, help="scenarios per GPU")
+    ap.add_argument("--workload", choices=["lattice", "pipeline"], default="lattice",
+                    help="lattice: batched SL path DP (64x128 lattice, 50 obstacles) + ST speed DP; "
+                         "pipeline: the whole replan on curved reference lines with 256 obstacles")
     ap.add_argument("--cpu-sample", type=int, default=192, help="scenarios timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--early-exit", type=int, default=0, help="1 = stop a scenario at its first failing layer")
@@ -133,6 +291,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload == "pipeline":
+        bench_pipeline(args, world, rank, backend)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     B = args.scenarios
     sc = make_scenarios(rank * B, B)
     sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])

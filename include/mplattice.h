@@ -191,8 +191,9 @@ int mp_curve_eval(int32_t B, const double *knots_t, const double *knots_x, const
 /* Replaces CartesianFrenetConverter.cartesian_to_frenet
  * (Model/cartesian_frenet_conversion.py:32-53) + Curve.projection
  * (Model/curve.py:117-126) for n_pts query points; point i belongs to scenario
- * pt_scn[i] and reads that scenario's tables.  vx/vy/s_dt may all be NULL
- * (order 0). */
+ * pt_scn[i] and reads that scenario's tables (as mp_refline_tables wrote them:
+ * the nearest-sample search relies on tab_x ascending).  vx/vy/s_dt may all be
+ * NULL (order 0). */
 int mp_c2f_batch(int32_t n_pts, const double *px, const double *py, const double *vx,
                  const double *vy, const int32_t *pt_scn, int32_t m_max, const double *tab_x,
                  const double *tab_y, const double *tab_s, const double *tab_theta,

@@ -14,13 +14,33 @@ __device__ __forceinline__ int c2f_point(const double *tx, const double *ty, con
                                          double *l_out)
 {
     // sqrt is monotone, so the smallest distance is the root of the smallest squared
-    // distance; the first sample that reaches it is the first one whose squared
-    // distance does not exceed the largest double with that same rounded root.
-    double m2 = MP_INF;
-    int k = 0;
-    for (int i = 0; i < M; ++i) {
+    // distance m2, and the first sample that reaches it is the first one whose squared
+    // distance does not exceed `top`, the largest double with that same rounded root.
+    // The abscissae ascend, so the search starts at the sample next to x and walks
+    // outwards on both sides only while (tx - x)^2 alone stays within the best value
+    // so far: a sample beyond that has d2 >= (tx - x)^2 > m2 and can neither win nor
+    // tie (the 1e-12 margin is far above the few ulps between m2 and top).
+    int i0 = 0;
+    if (M > 1) {
+        const double q = (x - tx[0]) / (tx[1] - tx[0]);
+        i0 = q > 0.0 ? (q < (double)(M - 1) ? (int)q : M - 1) : 0;
+    }
+    auto dist2 = [&](int i, double *dx2) {
         const double dx = tx[i] - x, dy = ty[i] - y;
-        const double d2 = dx * dx + dy * dy;
+        *dx2 = dx * dx;
+        return *dx2 + dy * dy;
+    };
+    double dx2;
+    double m2 = dist2(i0, &dx2);
+    int k = i0;
+    for (int i = i0 - 1; i >= 0; --i) {
+        const double d2 = dist2(i, &dx2);
+        if (dx2 > m2 * (1.0 + 1e-12)) break;
+        if (d2 <= m2) { m2 = d2; k = i; } // equal squared distances: the lower index
+    }
+    for (int i = i0 + 1; i < M; ++i) {
+        const double d2 = dist2(i, &dx2);
+        if (dx2 > m2 * (1.0 + 1e-12)) break;
         if (d2 < m2) { m2 = d2; k = i; }
     }
     const double best = __dsqrt_rn(m2);
@@ -30,9 +50,10 @@ __device__ __forceinline__ int c2f_point(const double *tx, const double *ty, con
         if (__dsqrt_rn(nx) == best) top = nx; else break;
     }
     if (top > m2) {
-        for (int i = 0; i < k; ++i) {
-            const double dx = tx[i] - x, dy = ty[i] - y;
-            if (dx * dx + dy * dy <= top) { k = i; break; }
+        for (int i = k - 1; i >= 0; --i) {
+            const double d2 = dist2(i, &dx2);
+            if (dx2 > top) break;
+            if (d2 <= top) k = i;
         }
     }
     const double th = tth[k];
