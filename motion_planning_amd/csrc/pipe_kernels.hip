@@ -38,7 +38,23 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
 #define NOB(d) ((d).n_st_max + (d).n_dy_max * (d).n_frames > 0 ? (d).n_st_max + (d).n_dy_max * (d).n_frames : 1)
 #define ONE(n) ((n) > 0 ? (n) : 1)
 #define OPT(d, n) ((d).want_maps ? (n) : 0)
+// The first PLAN_N_ZEROED arrays are cleared by one memset at the start of every call
+// (result rows whose unused tails no kernel writes, and the zero inputs).
+#define PLAN_N_ZEROED 13
 #define PLAN_ARRAYS(X)                                                                       \
+    X(zeros, double, MP_F64, d.B, 2, 1, 1)                                                   \
+    X(s_layers, double, MP_F64, d.B, d.n_s_max, 1, 1)                                        \
+    X(knots_t, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
+    X(knots_v, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
+    X(path_s, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
+    X(path_l, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
+    X(sp_t, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
+    X(sp_s, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
+    X(prof_t, double, MP_F64, d.B, d.q_max, 1, 1)                                            \
+    X(ss, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
+    X(vv, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
+    X(final_s, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
+    X(final_l, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
     X(status, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
     X(tab_x, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
     X(tab_y, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
@@ -53,7 +69,6 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(inv_y, double, MP_F64, d.B, d.m_max, 1, 1)                                             \
     X(inv_theta, double, MP_F64, d.B, d.m_max, 1, 1)                                         \
     X(n_inv, int32_t, MP_I32, d.B, 1, 1, 1)                                                  \
-    X(zeros, double, MP_F64, d.B, 2, 1, 1)                                                   \
     X(ego_sl, double, MP_F64, d.B, 2, 1, 1)                                                  \
     X(robot_vel, double, MP_F64, d.B, 1, 1, 1)                                               \
     X(st_s, double, MP_F64, d.B, ONE(d.n_st_max), 1, 1)                                      \
@@ -64,7 +79,6 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(ob_l, double, MP_F64, d.B, NOB(d), 1, 1)                                               \
     X(n_ob, int32_t, MP_I32, d.B, 1, 1, 1)                                                   \
     X(ob_dist, double, MP_F64, d.B, 1, 1, 1)                                                 \
-    X(s_layers, double, MP_F64, d.B, d.n_s_max, 1, 1)                                        \
     X(n_layers, int32_t, MP_I32, d.B, 1, 1, 1)                                               \
     X(l_row, double, MP_F64, d.n_l, 1, 1, 1)                                                 \
     X(path_idx, int32_t, MP_I32, d.B, d.n_s_max, 1, 1)                                       \
@@ -73,11 +87,7 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(best_cost, double, MP_F64, d.B, 1, 1, 1)                                               \
     X(cost_map, double, MP_F64, OPT(d, d.B), d.n_s_max, d.n_l, 1)                            \
     X(index_map, int32_t, MP_I32, OPT(d, d.B), d.n_s_max, d.n_l, 1)                          \
-    X(knots_t, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
-    X(knots_v, double, MP_F64, d.B, d.n_s_max + 1, 1, 1)                                     \
     X(n_pk, int32_t, MP_I32, d.B, 1, 1, 1)                                                   \
-    X(path_s, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
-    X(path_l, double, MP_F64, d.B, d.p_max, 1, 1)                                            \
     X(n_path, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
     X(path_status, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
     X(st_n_s, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
@@ -89,15 +99,8 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(st_path_len, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
     X(st_cost, double, MP_F64, OPT(d, d.B), d.n_t, d.st_n_s_max, 1)                          \
     X(st_pre, int32_t, MP_I32, OPT(d, d.B), d.n_t, d.st_n_s_max, 1)                          \
-    X(sp_t, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
-    X(sp_s, double, MP_F64, d.B, d.n_t, 1, 1)                                                \
-    X(prof_t, double, MP_F64, d.B, d.q_max, 1, 1)                                            \
-    X(ss, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
-    X(vv, double, MP_F64, d.B, d.q_max, 1, 1)                                                \
     X(n_prof, int32_t, MP_I32, d.B, 1, 1, 1)                                                 \
     X(prof_status, int32_t, MP_I32, d.B, 1, 1, 1)                                            \
-    X(final_s, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
-    X(final_l, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
     X(n_final, int32_t, MP_I32, d.B, 1, 1, 1)                                                \
     X(final_status, int32_t, MP_I32, d.B, 1, 1, 1)                                           \
     X(final_x, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
@@ -510,17 +513,12 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
     const int mid_l = p.sl.mid_l >= 0 ? p.sl.mid_l : (int)((d.n_l - 1) / 2);
     if (mid_l >= d.n_l) { mp_set_error("mid_l out of range"); return MP_E_BADARG; }
 
-    // result rows whose tails nobody writes start from zero
-    struct { void *p; int64_t n; } clr[] = {
-        {o.zeros, (int64_t)B * 2 * 8}, // the ego position (0, 0) and the path spline's end slope
-        {o.path_s, (int64_t)B * d.p_max * 8}, {o.path_l, (int64_t)B * d.p_max * 8},
-        {o.prof_t, (int64_t)B * d.q_max * 8}, {o.ss, (int64_t)B * d.q_max * 8}, {o.vv, (int64_t)B * d.q_max * 8},
-        {o.final_s, (int64_t)B * d.q_max * 8}, {o.final_l, (int64_t)B * d.q_max * 8},
-        {o.sp_t, (int64_t)B * d.n_t * 8}, {o.sp_s, (int64_t)B * d.n_t * 8},
-        {o.knots_t, (int64_t)B * (d.n_s_max + 1) * 8}, {o.knots_v, (int64_t)B * (d.n_s_max + 1) * 8},
-        {o.s_layers, (int64_t)B * d.n_s_max * 8},
-    };
-    for (auto &c : clr) (void)hipMemsetAsync(c.p, 0, (size_t)c.n, st);
+    // result rows whose tails nobody writes start from zero ("zeros" doubles as the ego
+    // position (0, 0) and as the path spline's end slope)
+    if (hipMemsetAsync(arena, 0, (size_t)tab[PLAN_N_ZEROED].offset, st) != hipSuccess) {
+        mp_set_error("mp_plan_scenes: memset failed");
+        return MP_E_LAUNCH;
+    }
 
     // 1. Frenet frame of every scene, the ego at the robot frame's origin
     rc = mp_refline_tables(B, in.knots_x, in.knots_y, in.n_knots, d.n_knots_max, in.line_vec, o.zeros, p.d_x,
