@@ -212,9 +212,12 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     __syncthreads();
     const int r = tid & (ST_SPLIT - 1), g = tid / ST_SPLIT, G = nt / ST_SPLIT;
     double m_loc = MP_INF;
+    // cells are taken from the far end downwards: whatever is left over for the last,
+    // partly filled pass are then the cells next to s = 0, which have the fewest
+    // predecessors, instead of the ones with the most
     for (int jb = 0; jb < n_s; jb += G) {
-        const int j = jb + g;
-        const bool live = j < n_s;
+        const int j = n_s - 1 - (jb + g);
+        const bool live = j >= 0;
         double best = MP_INF;
         int bp = 0x7fffffff;
         if (live) {
