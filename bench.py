@@ -264,7 +264,7 @@ def main():
     ap.add_argument("--workload", choices=["lattice", "pipeline"], default="lattice",
                     help="lattice: batched SL path DP (64x128 lattice, 50 obstacles) + ST speed DP; "
                          "pipeline: the whole replan on curved reference lines with 256 obstacles")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="scenarios timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=448, help="scenarios timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--early-exit", type=int, default=0, help="1 = stop a scenario at its first failing layer")
     ap.add_argument("--maps", type=int, default=0, help="1 = also write cost_map/index_map/ST tables to HBM")

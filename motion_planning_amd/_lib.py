@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
+MP_VERSION = 110   # MP_VERSION of include/mplattice.h this binding was written for
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3

@@ -26,7 +26,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
         assert s in _lib.SIGNATURES, "no ctypes signature for " + s
     assert set(_lib.SIGNATURES) == set(syms)
-    assert L.mp_version() == 110
+    assert L.mp_version() == _lib.MP_VERSION
+    hdr = open(os.path.join(ROOT, "include", "mplattice.h")).read()
+    assert int(re.search(r"#define MP_VERSION (\d+)", hdr).group(1)) == _lib.MP_VERSION
 
 
 def test_host_side_argument_errors_need_no_gpu():
