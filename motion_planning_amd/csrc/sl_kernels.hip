@@ -613,7 +613,7 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     const double r = a.in.ob_dist[b], r2 = r * r;
     const double rr = r * 1.000001 + 1e-9; // span test with slack; the pair test itself is exact
     const double d_s = a.p.d_s, w_d = a.p.w_d;
-    const double inv_ds = 1.0 / d_s, k_half = r * inv_ds + 2.5;
+    const double inv_ds = 1.0 / d_s, k_half = r * inv_ds + 0.75; // window slack: 3/4 of a sample spacing
     const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;
     const double pen = 3.0 * a.p.no_path_cost, abort_thr = 10.0 * a.p.no_path_cost;
     const int mid_l = a.p.mid_l;
@@ -708,8 +708,9 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
                                                     __builtin_amdgcn_readlane(__double2loint(os), sl));
                 const double uol = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ol), sl),
                                                     __builtin_amdgcn_readlane(__double2loint(ol), sl));
-                // samples that can lie within ob_dist of the obstacle (a generous index
-                // window on the regular grid; the appended end point is tested on its own)
+                // samples that can lie within ob_dist of the obstacle: grid sample k sits at
+                // p1s + k*d_s up to rounding, so only |k - c| < r/d_s can pass (the window adds
+                // slack; the appended end point is tested on its own)
                 int k_lo = 0, k_hi = K - 1;
                 if (K > 8) {
                     const double c = (uos - p1s) * inv_ds;
