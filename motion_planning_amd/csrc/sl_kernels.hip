@@ -45,6 +45,7 @@ struct SlDev {
     int32_t *layers_done;
     double *best_cost;
     double *edge_cost; // edge-tensor kernel only
+    int32_t pair_cap;  // fused kernel: (sample, obstacle) pairs the LDS pair store holds per scenario
 };
 
 struct LayerGeom {
@@ -104,21 +105,18 @@ __device__ __forceinline__ LayerConst layer_const(const LayerGeom &g, double p1s
     return c;
 }
 
-// Appends the (sample k, obstacle) pairs of one obstacle with |x_k - os| < ob_dist
-// to the LDS pair list (arbitrary order; the collision test is an OR).  Only
-// the samples around the obstacle are visited (the index window is
-// conservative, the test itself uses the exact abscissa).  *n_ent may exceed
-// SL_E_CAP: entries beyond the capacity are dropped and callers fall back to
-// testing every pair directly.
-__device__ __forceinline__ void add_obstacle_entries(int *n_ent, const LayerGeom &g, double p1s, double p2s,
-                                                     double d_s, double *e_h0, double *e_ol, double *e_ds2,
-                                                     double os, double ol, double r, double r2)
+// Calls f(k, x_k, (x_k - os)^2) for every sample k of a layer whose arc length lies
+// within ob_dist of the obstacle's.  Only the samples around the obstacle are
+// visited (the index window is conservative, the test itself uses the exact
+// abscissa).
+template <class F>
+__device__ __forceinline__ void for_each_near_sample(const LayerGeom &g, double p1s, double p2s, double d_s,
+                                                     double os, double r, double r2, F f)
 {
     // samples lie in [p1s, p2s] up to rounding: an obstacle further than
     // ob_dist (plus slack) from that span cannot produce a pair
     const double rr = r * 1.000001 + 1e-9;
     if (os < p1s - rr || os > p2s + rr) return;
-    const double T = p2s - p1s;
     int k_lo = 0, k_hi = g.K - 1;
     if (g.K > 8) {
         const double c = (os - p1s) / d_s, w = r / d_s + 2.0;
@@ -129,17 +127,29 @@ __device__ __forceinline__ void add_obstacle_entries(int *n_ent, const LayerGeom
         const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
         const double ds = x - os;
         const double ds2 = ds * ds;
-        if (ds2 < r2) {
-            const int slot = atomicAdd(n_ent, 1);
-            if (slot < SL_E_CAP) {
-                e_h0[slot] = basis_h0(x, T);
-                e_ol[slot] = ol;
-                e_ds2[slot] = ds2;
-            }
-        }
+        if (ds2 < r2) f(k, x, ds2);
     };
     for (int k = k_lo; k <= k_hi; ++k) test(k);
     if (k_hi < g.K - 1) test(g.K - 1); // the appended end point sits off the grid
+}
+
+// Appends the (sample k, obstacle) pairs of one obstacle to the LDS pair list of a
+// layer (arbitrary order; the collision test is an OR).  *n_ent may exceed
+// SL_E_CAP: entries beyond the capacity are dropped and callers fall back to
+// testing every pair directly.
+__device__ __forceinline__ void add_obstacle_entries(int *n_ent, const LayerGeom &g, double p1s, double p2s,
+                                                     double d_s, double *e_h0, double *e_ol, double *e_ds2,
+                                                     double os, double ol, double r, double r2)
+{
+    const double T = p2s - p1s;
+    for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double x, double ds2) {
+        const int slot = atomicAdd(n_ent, 1);
+        if (slot < SL_E_CAP) {
+            e_h0[slot] = basis_h0(x, T);
+            e_ol[slot] = ol;
+            e_ds2[slot] = ds2;
+        }
+    });
 }
 
 // Pair list of one layer, obstacles strided over the workgroup starting at
@@ -229,9 +239,10 @@ __device__ __forceinline__ double edge_closed_form(double dl, double g, double u
 // reading consecutive sources touch every bank once.
 struct SrcSh {
     double2 *lc;   // (lateral offset of the source node, its accumulated cost)
-    double *g;     // straight-edge guide cost of the source node
     double mid;    // centre of the source row
     double two_cga; // 2*cG*A of the layer
+    int K;         // samples per edge of the layer
+    double w_d, d_s;
 };
 
 // Relaxes target l2 = threadIdx.x (lateral offset l2v) of layer s: nearest
@@ -245,8 +256,8 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
 {
     const int l2 = threadIdx.x;
     auto eval = [&](int j, double l1, double cp, double dl) {
-        const double ua = src.two_cga * (l1 - src.mid);
-        double e = edge_closed_form(dl, src.g[j], ua, Q);
+        const double u = l1 - src.mid;
+        double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
         e += col.hit(l1, dl) ? pen : 0.0;
         return e + cp;
     };
@@ -311,17 +322,19 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 }
 
 // Fused SL plan: one workgroup per scenario (one thread per lane of the lattice)
-// walks the layers; edge costs never leave the chip.  A prologue computes every
-// layer's constants in parallel (one thread per layer) and keeps each thread's
-// obstacle in registers.  Inside the layer loop a thread relaxes its target and
-// straight away prepares the next layer's source-side data (its own node as a
-// source, the next pair list) in the other half of double-buffered LDS arrays,
-// so a layer costs one barrier and touches no global memory unless the lateral
+// walks the layers; edge costs never leave the chip.  A prologue computes, in
+// parallel, every layer's constants (one thread per layer) and the (sample,
+// obstacle) pairs of EVERY layer (one thread per obstacle: count per layer,
+// prefix sum, fill), so that nothing about obstacles is left to do inside the
+// sequential layer loop: there a thread relaxes its target, publishes its node
+// as a source of the next layer in the other half of a double-buffered LDS array,
+// and a layer costs one barrier and touches no global memory unless the lateral
 // grid changes from layer to layer (that row is prefetched a layer ahead).
-// Dynamic LDS layout (n_lp = n_l rounded up to even):
-//   lc[2][n_lp] double2 | g[2][n_lp] | layA layQ layW layP2 layMid [n_s] each
-//   ent[2][3][E_CAP] | red[2][8] | layK[n_s] int (K, bit 16: end point appended) | misc[4] int
-//   laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
+// Dynamic LDS layout (n_lp = n_l rounded up to even, cap = pair_cap):
+//   lc[2][n_lp] double2 | layA layQ layW layP2 layMid [n_s] each | pairs[3][cap] (basis value,
+//   obstacle offset, squared arc-length gap) | red[2][8] | layK[n_s] int (K, bit 16: end point
+//   appended) | cntL[n_s] int (pairs per layer) | offL[n_s] u16 (first pair of the layer)
+//   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
 __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
@@ -330,18 +343,19 @@ __global__ void sl_plan_kernel(SlDev a)
     const int n_s = scenario_layers(a.in, b);  // layers this scenario uses
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     const int n_lp = (n_l + 1) & ~1; // keeps the double2 arrays 16-byte aligned
+    const int cap = a.pair_cap;
     double2 *lc_all = (double2 *)smem;
-    double *g_all = (double *)(lc_all + 2 * n_lp);
-    double *layA = g_all + 2 * n_lp;
+    double *layA = (double *)(lc_all + 2 * n_lp);
     double *layQ = layA + n_sm;
     double *layW = layQ + n_sm;
     double *layP2 = layW + n_sm;
     double *layMid = layP2 + n_sm;
-    double *ent = layMid + n_sm;
-    double *red = ent + 6 * SL_E_CAP;
+    double *pair_h0 = layMid + n_sm, *pair_ol = pair_h0 + cap, *pair_ds2 = pair_ol + cap;
+    double *red = pair_ds2 + cap;
     int *layK = (int *)(red + 16);
-    int *misc = layK + n_sm; // pair counters, used round-robin over [0..2]
-    unsigned char *laySorted = (unsigned char *)(misc + 4);
+    int *cntL = layK + n_sm;
+    unsigned short *offL = (unsigned short *)(cntL + n_sm);
+    unsigned char *laySorted = (unsigned char *)(offL + n_sm + (n_sm & 1));
     unsigned char *idx8 = laySorted + ((n_sm + 3) & ~3);
 
     if (n_s <= 0) { // nothing to plan for this scenario
@@ -373,6 +387,7 @@ __global__ void sl_plan_kernel(SlDev a)
         layP2[s] = p2s;
         layMid[s] = lbase[(size_t)s * rstride + mid_l];
         laySorted[s] = 1;
+        cntL[s] = 0;
         if (g.K >= 0) {
             const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
             layA[s] = c.A;
@@ -382,7 +397,6 @@ __global__ void sl_plan_kernel(SlDev a)
             layW[s] = (c.cSH > 0.0 && c.Q <= 1e5 * c.cSH) ? (1.0 + 1e-9) / (c.cSH * (1.0 - 1e-9)) : 0.0;
         }
     }
-    if (tid == 0) misc[0] = misc[1] = misc[2] = 0;
     __syncthreads();
     {
         // largest |l - mid| over the lattice (bounds every straight-edge cost)
@@ -411,29 +425,98 @@ __global__ void sl_plan_kernel(SlDev a)
         g.delta = (p1s + d_s) - p1s;
         return g;
     };
-    // pair list of layer s into half (s & 1) of ent, counter misc[s % 3]
-    auto make_entries = [&](int s, const LayerGeom &g) {
-        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
-        const double p2s = layP2[s];
-        double *e_h0 = ent + (s & 1) * 3 * SL_E_CAP, *e_ol = e_h0 + SL_E_CAP, *e_ds2 = e_ol + SL_E_CAP;
-        int *cnt = misc + s % 3;
-        if (has_ob) add_obstacle_entries(cnt, g, p1s, p2s, d_s, e_h0, e_ol, e_ds2, my_os, my_ol, r, r2);
-        build_entries(cnt, g, p1s, p2s, d_s, e_h0, e_ol, e_ds2, ob_s, ob_l, n_ob, r, r2, tid + nt);
-    };
-    // layer 0: the ego is the only source (guide term relative to the last row's
-    // centre, as the reference's index -1 picks it)
-    {
-        const LayerGeom g0 = layer_geo(0);
-        if (g0.K >= 0) {
-            if (tid == 0) {
-                const double u = ego_l - layMid[n_s - 1];
-                lc_all[0] = make_double2(ego_l, 0.0);
-                g_all[0] = guide_straight(u, g0.K, w_d, d_s);
+    // ---- prologue: the (sample, obstacle) pairs of every layer --------------------
+    // f(s, g, p1s, p2s, os, ol) for every obstacle of this thread and every valid layer
+    // whose span the obstacle can reach.  The lanes first look through the layers
+    // together (a cheap span test), each noting where ITS layers start; the work then
+    // runs per lane on its own layers, so a wave takes as many steps as its busiest
+    // obstacle has layers (2-3), not one step per layer of the lattice.
+    auto each_obstacle_layer = [&](int s_begin, auto f) {
+        const double rr = r * 1.000001 + 1e-9;
+        auto in_span = [&](int s, double os) {
+            const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+            return !(os < p1s - rr || os > layP2[s] + rr);
+        };
+        auto visit = [&](int s, double os, double ol) {
+            const LayerGeom g = layer_geo(s);
+            if (g.K >= 0) f(s, g, (s == 0) ? ego_s : layP2[s - 1], layP2[s], os, ol);
+        };
+        auto one = [&](bool active, double os, double ol) {
+            int s_first = 0, cnt = 0;
+            bool contiguous = true;
+            double p1s = (s_begin == 0) ? ego_s : layP2[s_begin - 1];
+            for (int s = s_begin; s < n_s; ++s) {
+                const double p2s = layP2[s];
+                if (active && !(os < p1s - rr || os > p2s + rr)) {
+                    if (cnt == 0) s_first = s;
+                    else if (s != s_first + cnt) contiguous = false;
+                    ++cnt;
+                }
+                p1s = p2s;
             }
-            make_entries(0, g0);
+            if (contiguous) {
+                for (int q = 0; q < cnt; ++q) visit(s_first + q, os, ol);
+            } else { // layers out of order: take them one by one
+                for (int s = s_begin; s < n_s; ++s)
+                    if (in_span(s, os)) visit(s, os, ol);
+            }
+        };
+        // every lane of a wave enters `one` the same number of times
+        one(has_ob, my_os, my_ol);
+        for (int o0 = nt; o0 < n_ob; o0 += nt) {
+            const int o = o0 + tid;
+            const bool act = o < n_ob;
+            one(act, act ? ob_s[o] : 0.0, act ? ob_l[o] : 0.0);
         }
-    }
+    };
+    each_obstacle_layer(0, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double) {
+        int c = 0;
+        for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double, double) { ++c; });
+        if (c) atomicAdd(&cntL[s], c);
+    });
     __syncthreads();
+    // Lays the pairs of layers s_begin.. into the store from its start (cntL holds their
+    // counts): layers that do not fit any more are laid out again, from the first of
+    // them, when the layer loop gets there.  Every thread calls this.
+    auto place_pairs = [&](int s_begin) {
+        if (tid < MP_WAVE) {
+            // first pair of every layer: exclusive prefix sum of the counts, by one wave;
+            // the counters of the layers that get stored restart from 0 for the fill pass
+            int carry = 0;
+            for (int s0 = s_begin; s0 < n_s; s0 += MP_WAVE) {
+                const int s = s0 + tid;
+                const int c = s < n_s ? cntL[s] : 0;
+                int incl = c;
+                for (int m = 1; m < MP_WAVE; m <<= 1) {
+                    const int up = __shfl_up(incl, m, MP_WAVE);
+                    if (tid >= m) incl += up;
+                }
+                if (s < n_s) {
+                    const int off = carry + incl - c;
+                    offL[s] = (unsigned short)(off < cap ? off : cap);
+                    if (off < cap) cntL[s] = 0; // layers past the end of the store keep their count
+                }
+                carry += __shfl(incl, MP_WAVE - 1, MP_WAVE);
+            }
+        }
+        __syncthreads();
+        each_obstacle_layer(s_begin, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double ol) {
+            const double T = p2s - p1s;
+            const int off = offL[s];
+            if (off >= cap) return; // not stored this time
+            for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double x, double ds2) {
+                const int slot = off + atomicAdd(&cntL[s], 1);
+                if (slot < cap) {
+                    pair_h0[slot] = basis_h0(x, T);
+                    pair_ol[slot] = ol;
+                    pair_ds2[slot] = ds2;
+                }
+            });
+        });
+        __syncthreads();
+    };
+    if (tid == 0) lc_all[0] = make_double2(ego_l, 0.0); // layer 0: the ego is the only source
+    place_pairs(0);
     double u_max = red[0];
     for (int w = 1; w < nw; ++w) u_max = red[w] > u_max ? red[w] : u_max;
     const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
@@ -457,8 +540,15 @@ __global__ void sl_plan_kernel(SlDev a)
         const LayerGeom geo = layer_geo(s);
         if (geo.K < 0) { status = geo.K; break; }
         const int n_src = (s == 0) ? 1 : n_l;
-        const int n_ent = misc[s % 3];
-        if (tid == 0) misc[(s + 2) % 3] = 0; // counter of the layer after next
+        int n_ent = cntL[s], ent_off = offL[s];
+        if (ent_off > 0 && ent_off + n_ent > cap) {
+            // the store ran full before this layer: lay out the remaining layers from here
+            __syncthreads();
+            place_pairs(s);
+            n_ent = cntL[s];
+            ent_off = offL[s];
+        }
+        const bool ent_stored = ent_off + n_ent <= cap; // else (one layer alone too big): pairs are tested directly
         // next row of the lateral grid, in flight while this layer is relaxed
         double l_next = l_cur;
         if (rstride && is_target && s + 1 < n_s) l_next = lbase[(size_t)(s + 1) * rstride + tid];
@@ -468,10 +558,12 @@ __global__ void sl_plan_kernel(SlDev a)
         const bool sorted = s == 0 || laySorted[rstride ? s - 1 : 0] != 0;
         SrcSh src;
         src.lc = lc_all + buf * n_lp;
-        src.g = g_all + buf * n_lp;
-        src.mid = layMid[s == 0 ? n_s - 1 : s - 1];
+        src.mid = layMid[s == 0 ? n_s - 1 : s - 1]; // layer 0: the last row's centre, as index -1 picks it
         src.two_cga = 2.0 * cG * layA[s];
-        const double *e_h0 = ent + buf * 3 * SL_E_CAP, *e_ol = e_h0 + SL_E_CAP, *e_ds2 = e_ol + SL_E_CAP;
+        src.K = geo.K;
+        src.w_d = w_d;
+        src.d_s = d_s;
+        const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
         double best = MP_INF;
         int bj = 0;
         if (is_target) {
@@ -481,7 +573,7 @@ __global__ void sl_plan_kernel(SlDev a)
         col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);                    \
         best = relax_target<NE>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj);      \
     }
-            switch (n_ent) {
+            switch (ent_stored ? n_ent : -1) {
             case 0: SL_RELAX(0) break;
             case 1: SL_RELAX(1) break;
             case 2: SL_RELAX(2) break;
@@ -489,9 +581,8 @@ __global__ void sl_plan_kernel(SlDev a)
             case 4: SL_RELAX(4) break;
             case 5:
             case 6: SL_RELAX(6) break;
-            default: // rarely more than 6 pairs: the list is read from LDS
-                if (n_ent <= SL_E_CAP) SL_RELAX(-1) else SL_RELAX(-2)
-                break;
+            case -1: SL_RELAX(-2) break; // the pair store overflowed before this layer
+            default: SL_RELAX(-1) break; // more than 6 pairs: the list is read from LDS
             }
 #undef SL_RELAX
             idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
@@ -503,16 +594,6 @@ __global__ void sl_plan_kernel(SlDev a)
             lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
         }
         done = s + 1;
-        if (s + 1 < n_s) {
-            const LayerGeom gn = layer_geo(s + 1);
-            if (gn.K >= 0) {
-                if (is_target) {
-                    const double u = l_cur - layMid[s];
-                    g_all[(buf ^ 1) * n_lp + tid] = guide_straight(u, gn.K, w_d, d_s);
-                }
-                make_entries(s + 1, gn);
-            }
-        }
         best = wave_min_f64(best);
         if ((tid & (MP_WAVE - 1)) == 0) red[(buf ^ 1) * 8 + wave] = best;
         __syncthreads();
@@ -988,10 +1069,10 @@ __global__ void sl_dp_kernel(int n_sm, int n_l, const int32_t *n_layers, const d
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
-static size_t sl_plan_lds_bytes(int n_s, int n_l)
+static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
 {
-    size_t d = (size_t)6 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 6 * SL_E_CAP + 16;
-    size_t bytes = d * sizeof(double) + ((size_t)n_s + 4) * sizeof(int);
+    size_t d = (size_t)4 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 3 * (size_t)cap + 16;
+    size_t bytes = d * sizeof(double) + 2 * (size_t)n_s * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
     bytes += (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
@@ -1052,6 +1133,7 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.layers_done = layers_done;
     a.best_cost = best_cost;
     a.edge_cost = nullptr;
+    a.pair_cap = 0;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
     // well (the two must agree bit for bit; used by the tests)
     const char *narrow_env = getenv("MP_SL_NARROW");
@@ -1070,7 +1152,17 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
         }
         return launch_check("mp_sl_plan");
     }
-    const size_t lds = sl_plan_lds_bytes(n_s, n_l);
+    // pair store: 3.5 pairs per obstacle slot (an obstacle of radius r meets about
+    // 2r/d_s + 1 samples, a few of them twice where two layers share a sample),
+    // fewer if LDS would not hold it; layers past its end test their pairs directly
+    int cap = (7 * batch->ob_stride) / 2;
+    if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) cap = atoi(cap_env); // tests: force the overflow path
+    cap = cap < 2 ? 2 : (cap > 16384 ? 16384 : cap);
+    cap += cap & 1;
+    while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
+    a.pair_cap = cap;
+    const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
+    if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
     const int threads = ((n_l + 63) / 64) * 64;
     hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
     return launch_check("mp_sl_plan");
@@ -1099,6 +1191,7 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     a.layers_done = nullptr;
     a.best_cost = nullptr;
     a.edge_cost = edge_cost;
+    a.pair_cap = 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fill_i32_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, status, batch->B,
                        MP_SL_FOUND);

@@ -202,6 +202,28 @@ def test_sl_layer_count_per_scenario(oracle, n_l):
             assert np.array_equal(res[b]["path_idx"], res_split[b]["path_idx"])
 
 
+@pytest.mark.parametrize("cap", [2, 8, 40])
+def test_sl_pair_store_refill(oracle, cap, monkeypatch):
+    """The thread-per-node kernel keeps the (sample, obstacle) pairs of all layers in an LDS
+    store sized from the obstacle count; when it runs full the remaining layers are laid
+    out again, and a layer too big for the whole store tests its pairs directly.  A tiny
+    store forces both; results must not change."""
+    monkeypatch.setenv("MP_SL_PAIR_CAP", str(cap))
+    rng = np.random.default_rng(5 + cap)
+    B, n_s, n_l = 6, 14, 24
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 2.0, 30, 0.3, 0.9, None, True)
+    mid_l = int((n_l - 1) / 2)
+    for early in (True, False):
+        res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early)
+        res_split, _ = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early, split=True)
+        for b in range(B):
+            ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b],
+                                      no_early_exit=not early, want_edges=True)
+            assert_sl_parity(res[b], ref, ref.get("edge_cost"))
+            assert np.array_equal(res[b]["cost_map"], res_split[b]["cost_map"])
+            assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
+
+
 def test_sl_empty_edge_and_capacity_status():
     from motion_planning_amd import _lib
     s_map = np.array([[[8.0] * 5, [8.2] * 5]])            # second gap shorter than d_s
