@@ -222,6 +222,161 @@ struct Collider {
     }
 };
 
+// The (sample, obstacle) pairs of every layer of one scenario, kept in LDS for
+// the whole plan.  A pair is a sample of a layer whose arc length lies within
+// ob_dist of an obstacle's; it carries what the collision test needs (basis
+// value of the sample, lateral offset of the obstacle, squared arc-length gap).
+// Building them once, in parallel over the obstacles, leaves nothing about
+// obstacles to do inside the sequential layer loop:
+//   count()        every thread; adds each obstacle's pairs per layer to cntL
+//   place(s_begin) every thread; lays the pairs of layers s_begin.. into the store
+//                  from its start: prefix sum of the counts -> offL, then the fill.
+//                  Layers that do not fit any more keep their count and get
+//                  offL = cap; the layer loop calls place(s) again when it reaches
+//                  the first of them (the earlier layers' pairs are dead by then).
+//                  A layer that alone exceeds the store gets offL = PAIRS_TOO_MANY.
+// cntL must be zero before count(); the caller synchronises between the calls.
+#define PAIRS_TOO_MANY 0xFFFFu // offL of a layer that alone has more pairs than the store holds
+struct PairStore {
+    int n_s, n_ob, cap;
+    const double *ob_s, *ob_l;      // obstacles of the scenario (global memory)
+    bool has_ob;                    // this thread's first obstacle, held in registers
+    double my_os, my_ol;
+    double ego_s, d_s, r, r2;
+    const double *layP2;            // LDS: arc length of every layer
+    const int *layK;                // LDS: sample count code of every layer
+    int *cntL;                      // LDS: pairs per layer
+    unsigned short *offL;           // LDS: first pair of the layer in the store
+    double *h0, *ol, *ds2;          // LDS: the store, cap entries each
+
+    __device__ __forceinline__ LayerGeom geo(int s) const
+    {
+        LayerGeom g;
+        const int kn = layK[s];
+        g.K = kn < 0 ? kn : (kn & 0xffff);
+        g.n = kn < 0 ? 0 : g.K - (kn >> 16);
+        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
+        g.delta = (p1s + d_s) - p1s;
+        return g;
+    }
+
+    // f(s, g, p1s, p2s, os, ol) for every obstacle of this thread and every valid
+    // layer >= s_begin whose span the obstacle can reach.  The lanes first look
+    // through the layers together (a cheap span test), each noting where ITS layers
+    // start; the work then runs per lane on its own layers, so a wave takes as many
+    // steps as its busiest obstacle has layers (2-3), not one per layer of the lattice.
+    template <class F>
+    __device__ __forceinline__ void each_obstacle_layer(int s_begin, F f) const
+    {
+        const double rr = r * 1.000001 + 1e-9;
+        auto visit = [&](int s, double os, double ol_) {
+            const LayerGeom g = geo(s);
+            if (g.K >= 0) f(s, g, (s == 0) ? ego_s : layP2[s - 1], layP2[s], os, ol_);
+        };
+        auto one = [&](bool active, double os, double ol_) {
+            int s_first = 0, cnt = 0;
+            bool contiguous = true;
+            double p1s = (s_begin == 0) ? ego_s : layP2[s_begin - 1];
+            for (int s = s_begin; s < n_s; ++s) {
+                const double p2s = layP2[s];
+                if (active && !(os < p1s - rr || os > p2s + rr)) {
+                    if (cnt == 0) s_first = s;
+                    else if (s != s_first + cnt) contiguous = false;
+                    ++cnt;
+                }
+                p1s = p2s;
+            }
+            if (contiguous) {
+                for (int q = 0; q < cnt; ++q) visit(s_first + q, os, ol_);
+            } else { // layers out of order: take them one by one
+                for (int s = s_begin; s < n_s; ++s) {
+                    const double q1 = (s == 0) ? ego_s : layP2[s - 1];
+                    if (!(os < q1 - rr || os > layP2[s] + rr)) visit(s, os, ol_);
+                }
+            }
+        };
+        // every lane of a wave enters `one` the same number of times
+        const int tid = threadIdx.x, nt = blockDim.x;
+        one(has_ob, my_os, my_ol);
+        for (int o0 = nt; o0 < n_ob; o0 += nt) {
+            const int o = o0 + tid;
+            const bool act = o < n_ob;
+            one(act, act ? ob_s[o] : 0.0, act ? ob_l[o] : 0.0);
+        }
+    }
+
+    __device__ __forceinline__ void count() const
+    {
+        each_obstacle_layer(0, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double) {
+            int c = 0;
+            for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double, double) { ++c; });
+            if (c) atomicAdd(&cntL[s], c);
+        });
+    }
+
+    __device__ __forceinline__ void place(int s_begin) const
+    {
+        const int tid = threadIdx.x;
+        if (tid < MP_WAVE) {
+            // first pair of every layer: exclusive prefix sum of the counts, by one wave;
+            // the counters of the layers that get stored restart from 0 for the fill pass
+            int carry = 0;
+            for (int s0 = s_begin; s0 < n_s; s0 += MP_WAVE) {
+                const int s = s0 + tid;
+                const int c = s < n_s ? cntL[s] : 0;
+                int incl = c;
+                for (int m = 1; m < MP_WAVE; m <<= 1) {
+                    const int up = __shfl_up(incl, m, MP_WAVE);
+                    if (tid >= m) incl += up;
+                }
+                if (s < n_s) {
+                    // only layers that fit entirely are stored (their counters restart for
+                    // the fill); the others keep their count
+                    const int off = carry + incl - c;
+                    if (off + c <= cap) {
+                        offL[s] = (unsigned short)off;
+                        cntL[s] = 0;
+                    } else {
+                        offL[s] = (s == s_begin) ? PAIRS_TOO_MANY : (unsigned short)cap;
+                    }
+                }
+                carry += __shfl(incl, MP_WAVE - 1, MP_WAVE);
+            }
+        }
+        __syncthreads();
+        if (offL[s_begin] == PAIRS_TOO_MANY) return; // nothing fits behind a layer that does not fit itself
+        each_obstacle_layer(s_begin, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double ol_) {
+            const double T = p2s - p1s;
+            const int off = offL[s];
+            if (off >= cap) return; // not stored this time
+            for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double x, double d2) {
+                const int slot = off + atomicAdd(&cntL[s], 1);
+                h0[slot] = basis_h0(x, T);
+                ol[slot] = ol_;
+                ds2[slot] = d2;
+            });
+        });
+        __syncthreads();
+    }
+
+    // Pairs of layer s for the layer loop (every thread, same values): lays the store
+    // out again from layer s if it ran full before it.  *stored = false when this one
+    // layer alone exceeds the store: its pairs must then be found another way.
+    __device__ __forceinline__ int layer_pairs(int s, int *off_out, bool *stored) const
+    {
+        int n = cntL[s], off = offL[s];
+        if (off != PAIRS_TOO_MANY && off + n > cap) {
+            __syncthreads();
+            place(s);
+            n = cntL[s];
+            off = offL[s];
+        }
+        *stored = off != PAIRS_TOO_MANY;
+        *off_out = *stored ? off : 0;
+        return n;
+    }
+};
+
 // Straight-edge guide cost w_d*(d_s*np.sum(K copies of (l1-mid)^2)).
 __device__ __forceinline__ double guide_straight(double u, int K, double w_d, double d_s)
 {
@@ -426,97 +581,17 @@ __global__ void sl_plan_kernel(SlDev a)
         return g;
     };
     // ---- prologue: the (sample, obstacle) pairs of every layer --------------------
-    // f(s, g, p1s, p2s, os, ol) for every obstacle of this thread and every valid layer
-    // whose span the obstacle can reach.  The lanes first look through the layers
-    // together (a cheap span test), each noting where ITS layers start; the work then
-    // runs per lane on its own layers, so a wave takes as many steps as its busiest
-    // obstacle has layers (2-3), not one step per layer of the lattice.
-    auto each_obstacle_layer = [&](int s_begin, auto f) {
-        const double rr = r * 1.000001 + 1e-9;
-        auto in_span = [&](int s, double os) {
-            const double p1s = (s == 0) ? ego_s : layP2[s - 1];
-            return !(os < p1s - rr || os > layP2[s] + rr);
-        };
-        auto visit = [&](int s, double os, double ol) {
-            const LayerGeom g = layer_geo(s);
-            if (g.K >= 0) f(s, g, (s == 0) ? ego_s : layP2[s - 1], layP2[s], os, ol);
-        };
-        auto one = [&](bool active, double os, double ol) {
-            int s_first = 0, cnt = 0;
-            bool contiguous = true;
-            double p1s = (s_begin == 0) ? ego_s : layP2[s_begin - 1];
-            for (int s = s_begin; s < n_s; ++s) {
-                const double p2s = layP2[s];
-                if (active && !(os < p1s - rr || os > p2s + rr)) {
-                    if (cnt == 0) s_first = s;
-                    else if (s != s_first + cnt) contiguous = false;
-                    ++cnt;
-                }
-                p1s = p2s;
-            }
-            if (contiguous) {
-                for (int q = 0; q < cnt; ++q) visit(s_first + q, os, ol);
-            } else { // layers out of order: take them one by one
-                for (int s = s_begin; s < n_s; ++s)
-                    if (in_span(s, os)) visit(s, os, ol);
-            }
-        };
-        // every lane of a wave enters `one` the same number of times
-        one(has_ob, my_os, my_ol);
-        for (int o0 = nt; o0 < n_ob; o0 += nt) {
-            const int o = o0 + tid;
-            const bool act = o < n_ob;
-            one(act, act ? ob_s[o] : 0.0, act ? ob_l[o] : 0.0);
-        }
-    };
-    each_obstacle_layer(0, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double) {
-        int c = 0;
-        for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double, double) { ++c; });
-        if (c) atomicAdd(&cntL[s], c);
-    });
+    PairStore ps;
+    ps.n_s = n_s; ps.n_ob = n_ob; ps.cap = cap;
+    ps.ob_s = ob_s; ps.ob_l = ob_l;
+    ps.has_ob = has_ob; ps.my_os = my_os; ps.my_ol = my_ol;
+    ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
+    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL;
+    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
+    ps.count();
     __syncthreads();
-    // Lays the pairs of layers s_begin.. into the store from its start (cntL holds their
-    // counts): layers that do not fit any more are laid out again, from the first of
-    // them, when the layer loop gets there.  Every thread calls this.
-    auto place_pairs = [&](int s_begin) {
-        if (tid < MP_WAVE) {
-            // first pair of every layer: exclusive prefix sum of the counts, by one wave;
-            // the counters of the layers that get stored restart from 0 for the fill pass
-            int carry = 0;
-            for (int s0 = s_begin; s0 < n_s; s0 += MP_WAVE) {
-                const int s = s0 + tid;
-                const int c = s < n_s ? cntL[s] : 0;
-                int incl = c;
-                for (int m = 1; m < MP_WAVE; m <<= 1) {
-                    const int up = __shfl_up(incl, m, MP_WAVE);
-                    if (tid >= m) incl += up;
-                }
-                if (s < n_s) {
-                    const int off = carry + incl - c;
-                    offL[s] = (unsigned short)(off < cap ? off : cap);
-                    if (off < cap) cntL[s] = 0; // layers past the end of the store keep their count
-                }
-                carry += __shfl(incl, MP_WAVE - 1, MP_WAVE);
-            }
-        }
-        __syncthreads();
-        each_obstacle_layer(s_begin, [&](int s, const LayerGeom &g, double p1s, double p2s, double os, double ol) {
-            const double T = p2s - p1s;
-            const int off = offL[s];
-            if (off >= cap) return; // not stored this time
-            for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double x, double ds2) {
-                const int slot = off + atomicAdd(&cntL[s], 1);
-                if (slot < cap) {
-                    pair_h0[slot] = basis_h0(x, T);
-                    pair_ol[slot] = ol;
-                    pair_ds2[slot] = ds2;
-                }
-            });
-        });
-        __syncthreads();
-    };
     if (tid == 0) lc_all[0] = make_double2(ego_l, 0.0); // layer 0: the ego is the only source
-    place_pairs(0);
+    ps.place(0);
     double u_max = red[0];
     for (int w = 1; w < nw; ++w) u_max = red[w] > u_max ? red[w] : u_max;
     const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
@@ -540,15 +615,9 @@ __global__ void sl_plan_kernel(SlDev a)
         const LayerGeom geo = layer_geo(s);
         if (geo.K < 0) { status = geo.K; break; }
         const int n_src = (s == 0) ? 1 : n_l;
-        int n_ent = cntL[s], ent_off = offL[s];
-        if (ent_off > 0 && ent_off + n_ent > cap) {
-            // the store ran full before this layer: lay out the remaining layers from here
-            __syncthreads();
-            place_pairs(s);
-            n_ent = cntL[s];
-            ent_off = offL[s];
-        }
-        const bool ent_stored = ent_off + n_ent <= cap; // else (one layer alone too big): pairs are tested directly
+        int ent_off;
+        bool ent_stored;
+        const int n_ent = ps.layer_pairs(s, &ent_off, &ent_stored);
         // next row of the lateral grid, in flight while this layer is relaxed
         double l_next = l_cur;
         if (rstride && is_target && s + 1 < n_s) l_next = lbase[(size_t)(s + 1) * rstride + tid];
@@ -650,17 +719,15 @@ __global__ void sl_plan_kernel(SlDev a)
 // EDGE instead of one thread per node.  Lane (t, j) = (tid / W, tid % W), W the
 // power of two >= n_l, holds the edge from source j to target t; the targets'
 // first minima come from a W-lane (cost, index) merge.  Every edge of a layer is
-// evaluated, so no pruning is needed, and the collision test runs obstacle by
-// obstacle for all edges at once: each round the lanes look at 64 obstacles,
-// a ballot keeps those whose arc length lies within ob_dist of the layer's span,
-// and for each of them (a wave-uniform loop) every lane tests its own edge at the
-// samples around the obstacle.  Work per layer is therefore proportional to the
-// obstacles that can touch the layer, however many the scenario has, and all
-// lanes are busy.  Sample abscissae and basis values of the layer sit in LDS,
-// built a layer ahead.  Same edge arithmetic as sl_plan_kernel, bit for bit.
-// Dynamic LDS (n_sm = layer slots):
-//   layA layQ layP2 layMid [n_sm] | xs[2][K_CAP] h0s[2][K_CAP] | lc[2][W] double2
-//   | g[2][W] | red[2][16] | layK[n_sm] int | idx8[n_sm*n_l] u8
+// evaluated, so no pruning is needed and all lanes are busy.  The (sample,
+// obstacle) pairs of all layers are laid out in LDS by the prologue (PairStore,
+// in parallel over the obstacles; the store is laid out again from the current
+// layer when a crowded scene fills it), so the collision test of a layer is one
+// loop over that layer's pairs, the same for every lane.  Same edge arithmetic as
+// sl_plan_kernel, bit for bit.
+// Dynamic LDS (n_sm = layer slots, cap = pair_cap):
+//   layA layQ layP2 layMid [n_sm] | pairs[3][cap] | lc[2][W] double2 | g[2][W] | red[2][16]
+//   | layK[n_sm] int | cntL[n_sm] int | offL[n_sm] u16 | idx8[n_sm*n_l] u8
 template <int W>
 __global__ void sl_plan_narrow_kernel(SlDev a)
 {
@@ -673,13 +740,16 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     double *layQ = layA + n_sm;
     double *layP2 = layQ + n_sm;
     double *layMid = layP2 + n_sm;
-    double *xs = layMid + n_sm + (n_sm & 1); // even offset: the double2 array below stays aligned
-    double *h0s = xs + 2 * MP_SL_K_CAP;
-    double2 *lc_all = (double2 *)(h0s + 2 * MP_SL_K_CAP);
+    const int cap = a.pair_cap; // even
+    double *pair_h0 = layMid + n_sm + (n_sm & 1); // even offset: the double2 array below stays aligned
+    double *pair_ol = pair_h0 + cap, *pair_ds2 = pair_ol + cap;
+    double2 *lc_all = (double2 *)(pair_ds2 + cap + (cap & 1));
     double *g_all = (double *)(lc_all + 2 * W);
     double *red = g_all + 2 * W;
     int *layK = (int *)(red + 32);
-    unsigned char *idx8 = (unsigned char *)(layK + n_sm);
+    int *cntL = layK + n_sm;
+    unsigned short *offL = (unsigned short *)(cntL + n_sm);
+    unsigned char *idx8 = (unsigned char *)(offL + n_sm + (n_sm & 1));
 
     if (n_s <= 0) {
         write_skipped(a, b, n_sm, n_l);
@@ -692,9 +762,7 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
     const int n_ob = a.in.n_ob[b];
     const double r = a.in.ob_dist[b], r2 = r * r;
-    const double rr = r * 1.000001 + 1e-9; // span test with slack; the pair test itself is exact
     const double d_s = a.p.d_s, w_d = a.p.w_d;
-    const double inv_ds = 1.0 / d_s, k_half = r * inv_ds + 0.75; // window slack: 3/4 of a sample spacing
     const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;
     const double pen = 3.0 * a.p.no_path_cost, abort_thr = 10.0 * a.p.no_path_cost;
     const int mid_l = a.p.mid_l;
@@ -708,12 +776,24 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
         layK[s] = g.K < 0 ? g.K : (g.K | ((g.n != g.K) << 16));
         layP2[s] = p2s;
         layMid[s] = lbase[(size_t)s * rstride + mid_l];
+        cntL[s] = 0;
         if (g.K >= 0) {
             const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
             layA[s] = c.A;
             layQ[s] = c.Q;
         }
     }
+    __syncthreads();
+    PairStore ps;
+    ps.n_s = n_s; ps.n_ob = n_ob; ps.cap = cap;
+    ps.ob_s = ob_s; ps.ob_l = ob_l;
+    ps.has_ob = tid < n_ob;
+    ps.my_os = ps.has_ob ? ob_s[tid] : 0.0;
+    ps.my_ol = ps.has_ob ? ob_l[tid] : 0.0;
+    ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
+    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL;
+    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
+    ps.count();
     __syncthreads();
     auto layer_geo = [&](int s) {
         LayerGeom g;
@@ -724,28 +804,14 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
         g.delta = (p1s + d_s) - p1s;
         return g;
     };
-    // abscissae and basis values of layer s into half (s & 1) of the sample tables
-    auto make_samples = [&](int s, const LayerGeom &g) {
-        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
-        const double p2s = layP2[s];
-        const double T = p2s - p1s;
-        for (int k = tid; k < g.K; k += nt) {
-            const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
-            xs[(s & 1) * MP_SL_K_CAP + k] = x;
-            h0s[(s & 1) * MP_SL_K_CAP + k] = basis_h0(x, T);
-        }
-    };
     {
         const LayerGeom g0 = layer_geo(0);
-        if (g0.K >= 0) {
-            if (tid == 0) {
-                lc_all[0] = make_double2(ego_l, 0.0);
-                g_all[0] = guide_straight(ego_l - layMid[n_s - 1], g0.K, w_d, d_s);
-            }
-            make_samples(0, g0);
+        if (g0.K >= 0 && tid == 0) {
+            lc_all[0] = make_double2(ego_l, 0.0);
+            g_all[0] = guide_straight(ego_l - layMid[n_s - 1], g0.K, w_d, d_s);
         }
     }
-    __syncthreads();
+    ps.place(0); // ends with a barrier
 
     int status = MP_SL_FOUND, done = 0;
     for (int s = 0; s < n_s; ++s) {
@@ -769,48 +835,73 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
         const double2 lcj = valid ? lc_all[buf * W + j] : make_double2(0.0, 0.0);
         const double gj = valid ? g_all[buf * W + j] : 0.0;
         const double dl = l2v - lcj.x;
-        const double *x_tab = xs + buf * MP_SL_K_CAP, *h_tab = h0s + buf * MP_SL_K_CAP;
-
+        int ent_off;
+        bool ent_stored;
+        const int n_ent = ps.layer_pairs(s, &ent_off, &ent_stored);
         bool hit = false;
-        for (int o0 = 0; o0 < n_ob; o0 += MP_WAVE) {
-            const int o = o0 + lane;
-            double os = 0.0, ol = 0.0;
-            bool near = false;
-            if (o < n_ob) {
-                os = ob_s[o];
-                ol = ob_l[o];
-                near = !(os < p1s - rr || os > p2s + rr);
+        if (ent_stored) {
+            const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
+            for (int e = 0; e < n_ent; ++e) hit |= pair_hit(lcj.x, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
+        } else if (3 * cap >= 2 * K) {
+            // This one layer has more pairs than the store holds (a very crowded scene).
+            // The store is idle then (the layers after it are laid out later), so it takes
+            // the layer's sample abscissae and basis values, and the obstacles are streamed:
+            // each round the lanes look at 64 obstacles, a ballot keeps those within reach
+            // of the layer's span, and for each of them (a wave-uniform loop) every lane
+            // tests its own edge at the samples around the obstacle.
+            double *x_tab = pair_h0, *h_tab = pair_h0 + K;
+            __syncthreads();
+            for (int k = tid; k < K; k += nt) {
+                const double x = arange_value(k, geo.n, p1s, p2s, d_s, geo.delta);
+                x_tab[k] = x;
+                h_tab[k] = basis_h0(x, p2s - p1s);
             }
-            unsigned long long m = __ballot(near);
-            while (m) {
-                const int sl = __builtin_ctzll(m);
-                m &= m - 1;
-                const double uos = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(os), sl),
-                                                    __builtin_amdgcn_readlane(__double2loint(os), sl));
-                const double uol = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ol), sl),
-                                                    __builtin_amdgcn_readlane(__double2loint(ol), sl));
-                // samples that can lie within ob_dist of the obstacle: grid sample k sits at
-                // p1s + k*d_s up to rounding, so only |k - c| < r/d_s can pass (the window adds
-                // slack; the appended end point is tested on its own)
-                int k_lo = 0, k_hi = K - 1;
-                if (K > 8) {
-                    const double c = (uos - p1s) * inv_ds;
-                    k_lo = (c - k_half > 0.0) ? (int)(c - k_half) : 0;
-                    k_hi = (c + k_half < (double)(K - 2)) ? (int)(c + k_half) : K - 2;
-                    k_lo = __builtin_amdgcn_readfirstlane(k_lo);
-                    k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+            __syncthreads();
+            const double rr = r * 1.000001 + 1e-9; // span test with slack; the pair test itself is exact
+            const double inv_ds = 1.0 / d_s, k_half = r * inv_ds + 0.75; // window slack: 3/4 of a spacing
+            for (int o0 = 0; o0 < n_ob; o0 += MP_WAVE) {
+                const int o = o0 + lane;
+                double os = 0.0, ol = 0.0;
+                bool near = false;
+                if (o < n_ob) {
+                    os = ob_s[o];
+                    ol = ob_l[o];
+                    near = !(os < p1s - rr || os > p2s + rr);
                 }
-                for (int k = k_lo; k <= k_hi; ++k) {
-                    const double ds = x_tab[k] - uos;
-                    const double ds2 = ds * ds;
-                    if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[k], uol, ds2, r2);
-                }
-                if (k_hi < K - 1) {
-                    const double ds = x_tab[K - 1] - uos;
-                    const double ds2 = ds * ds;
-                    if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[K - 1], uol, ds2, r2);
+                unsigned long long m = __ballot(near);
+                while (m) {
+                    const int sl = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double uos = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(os), sl),
+                                                        __builtin_amdgcn_readlane(__double2loint(os), sl));
+                    const double uol = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ol), sl),
+                                                        __builtin_amdgcn_readlane(__double2loint(ol), sl));
+                    // grid sample k sits at p1s + k*d_s up to rounding, so only |k - c| < r/d_s
+                    // can pass; the appended end point is tested on its own
+                    int k_lo = 0, k_hi = K - 1;
+                    if (K > 8) {
+                        const double c = (uos - p1s) * inv_ds;
+                        k_lo = (c - k_half > 0.0) ? (int)(c - k_half) : 0;
+                        k_hi = (c + k_half < (double)(K - 2)) ? (int)(c + k_half) : K - 2;
+                        k_lo = __builtin_amdgcn_readfirstlane(k_lo);
+                        k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+                    }
+                    for (int k = k_lo; k <= k_hi; ++k) {
+                        const double ds = x_tab[k] - uos;
+                        const double ds2 = ds * ds;
+                        if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[k], uol, ds2, r2);
+                    }
+                    if (k_hi < K - 1) {
+                        const double ds = x_tab[K - 1] - uos;
+                        const double ds2 = ds * ds;
+                        if (ds2 < r2) hit |= pair_hit(lcj.x, dl, h_tab[K - 1], uol, ds2, r2);
+                    }
                 }
             }
+        } else { // a store too small even for the sample tables: test every pair directly
+            Collider<-2> col;
+            col.init(nullptr, nullptr, nullptr, 0, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+            hit = col.hit(lcj.x, dl);
         }
 
         const double mid = layMid[s == 0 ? n_s - 1 : s - 1];
@@ -833,7 +924,6 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
             const LayerGeom gn = layer_geo(s + 1);
             if (gn.K >= 0) {
                 if (owner) g_all[(buf ^ 1) * W + t] = guide_straight(l2v - layMid[s], gn.K, w_d, d_s);
-                make_samples(s + 1, gn);
             }
         }
         const double bm = wave_min_f64(owner ? c : MP_INF);
@@ -1077,10 +1167,13 @@ static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
     return (bytes + 15) & ~(size_t)15;
 }
 
-static size_t sl_narrow_lds_bytes(int n_s, int n_l, int W)
+#define SLN_CAP_MAX 384 // narrow kernel: upper limit of its pair store (9 KB)
+
+static size_t sl_narrow_lds_bytes(int n_s, int n_l, int W, int cap)
 {
-    size_t d = (size_t)4 * n_s + (n_s & 1) + 4 * MP_SL_K_CAP + 4 * W + 2 * W + 32;
-    size_t bytes = d * sizeof(double) + (size_t)n_s * sizeof(int) + (size_t)n_s * n_l;
+    size_t d = (size_t)4 * n_s + (n_s & 1) + 3 * (size_t)cap + (cap & 1) + 4 * W + 2 * W + 32;
+    size_t bytes = d * sizeof(double) + 2 * (size_t)n_s * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short) +
+                   (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -1141,7 +1234,14 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     if (n_l <= 16 && narrow_ok) {
         const int W = n_l <= 2 ? 2 : (n_l <= 4 ? 4 : (n_l <= 8 ? 8 : 16));
         const int threads = ((n_l * W + 63) / 64) * 64;
-        const size_t lds = sl_narrow_lds_bytes(n_s, n_l, W);
+        int ncap = (7 * batch->ob_stride) / 2;
+        ncap = ncap > SLN_CAP_MAX ? SLN_CAP_MAX : ncap;
+        if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) ncap = atoi(cap_env); // tests: force refills
+        ncap = ncap < 2 ? 2 : (ncap > 2048 ? 2048 : ncap);
+        ncap += ncap & 1;
+        a.pair_cap = ncap;
+        const size_t lds = sl_narrow_lds_bytes(n_s, n_l, W, ncap);
+        if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: too many layers for LDS"); return MP_E_UNSUPPORTED; }
         const dim3 grid(batch->B), block(threads);
         hipStream_t st = (hipStream_t)stream;
         switch (W) {

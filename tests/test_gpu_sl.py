@@ -202,15 +202,16 @@ def test_sl_layer_count_per_scenario(oracle, n_l):
             assert np.array_equal(res[b]["path_idx"], res_split[b]["path_idx"])
 
 
+@pytest.mark.parametrize("n_l", [5, 12, 24])
 @pytest.mark.parametrize("cap", [2, 8, 40])
-def test_sl_pair_store_refill(oracle, cap, monkeypatch):
-    """The thread-per-node kernel keeps the (sample, obstacle) pairs of all layers in an LDS
-    store sized from the obstacle count; when it runs full the remaining layers are laid
-    out again, and a layer too big for the whole store tests its pairs directly.  A tiny
+def test_sl_pair_store_refill(oracle, cap, n_l, monkeypatch):
+    """Both fused kernels keep the (sample, obstacle) pairs of all layers in an LDS store
+    sized from the obstacle count; when it runs full the remaining layers are laid out
+    again, and a layer too big for the whole store tests its pairs directly.  A tiny
     store forces both; results must not change."""
     monkeypatch.setenv("MP_SL_PAIR_CAP", str(cap))
     rng = np.random.default_rng(5 + cap)
-    B, n_s, n_l = 6, 14, 24
+    B, n_s = 6, 14
     s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 2.0, 30, 0.3, 0.9, None, True)
     mid_l = int((n_l - 1) / 2)
     for early in (True, False):
