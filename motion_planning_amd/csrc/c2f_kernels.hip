@@ -22,6 +22,7 @@
 
 #define RL_SEG_CAP 128 // spline segments per reference line
 #define RL_ARC_CAP 128 // samples in one rectangle-rule piece
+#define RL_FT 16       // per segment: integrand values at 0, dt, 2dt, ... kept in LDS
 
 // Model/curve.py:130-157 QuinticPoly coefficients.
 __device__ void quintic_coef(double xs, double vxs, double axs, double xe, double vxe, double axe, double T,
@@ -63,6 +64,34 @@ __device__ __forceinline__ void curve_get_i(const double *T, int n, double t, in
     *tt = t_sum;
 }
 
+// curve_get_i with the running sums it accumulates kept in a table: Tseq[i] =
+// (((T[0] + T[1]) + ...) + T[i]), added in that order.  Positive segment lengths
+// make the table ascend, and the first i with t <= Tseq[i] is found by bisection;
+// otherwise by the same scan as curve_get_i.
+__device__ __forceinline__ void curve_get_i_tab(const double *Tseq, const double *T, int n, bool ascending,
+                                                double t, int *ii, double *tt)
+{
+    int i;
+    if (ascending) {
+        int lo = 0, hi = n; // first index with t <= Tseq[index], n if none
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t <= Tseq[mid]) hi = mid; else lo = mid + 1;
+        }
+        i = lo;
+    } else {
+        for (i = 0; i < n; ++i)
+            if (t <= Tseq[i]) break;
+    }
+    if (i < n) {
+        *ii = i;
+        *tt = t - Tseq[i] + T[i];
+    } else {
+        *ii = n - 1;
+        *tt = Tseq[n - 1];
+    }
+}
+
 // np.sum (pairwise order, n <= 128) over generated elements f(i).
 template <class F>
 __device__ __forceinline__ double np_sum_gen(int n, F f)
@@ -86,18 +115,30 @@ __device__ __forceinline__ double np_sum_gen(int n, F f)
 }
 
 // Model/curve.py:175-186 QuinticPoly.calc_arc_len for t0 <= t1; *bad is set
-// when the piece has more than RL_ARC_CAP samples.
-__device__ double quintic_arc_len(const double *a, double t0, double t1, double dt, int *bad)
+// when the piece has more than RL_ARC_CAP samples.  ftab (may be null): the
+// integrand sqrt(1 + x'(t)^2) of this segment at t = 0, dt, 2dt, ... (RL_FT
+// values).  A piece that starts at 0 samples exactly those abscissae plus its own
+// end point, so it takes them from the table and evaluates only the end point;
+// the sum runs in the same order either way.
+__device__ double quintic_arc_len(const double *a, double t0, double t1, double dt, int *bad,
+                                  const double *ftab = nullptr)
 {
     int n;
     double delta;
     const int K = arange_count(t0, t1, dt, RL_ARC_CAP, &n, &delta);
     if (K < 0) { *bad = 1; return 0.0; }
     if (K == 0) return 0.0;
-    double s = np_sum_gen(K, [&](int i) {
+    auto integrand = [&](int i) {
         double d = quintic_eval(a, arange_value(i, n, t0, t1, dt, delta), 1);
         return __dsqrt_rn(1 + d * d);
-    });
+    };
+    double s;
+    if (ftab && t0 == 0.0 && n <= RL_FT) {
+        const double f_end = (K > n) ? integrand(n) : 0.0; // the appended end point
+        s = np_sum_gen(K, [&](int i) { return i < n ? ftab[i] : f_end; });
+    } else {
+        s = np_sum_gen(K, integrand);
+    }
     return 1 * dt * s;
 }
 
@@ -115,23 +156,26 @@ struct RlDev {
     int32_t *n_inv;
 };
 
-// Curve.calc_arc_len(rx_ori, x) (curve.py:93-115) with the pieces every call
-// shares precomputed: the origin's segment (st_i, st_t) to its end and every
-// full segment.
-__device__ double arc_from_origin(const double *T, int n, const double *coef, const double *seg_full,
-                                  double first_piece, int st_i, double st_t, double t0, double t1, double dt,
-                                  int *bad)
+// Everything Curve.calc_arc_len(rx_ori, x) (curve.py:93-115) shares between calls,
+// in LDS: segment lengths and their running sums, spline coefficients, the
+// integrand table, and arc_pre[e] = the length from the origin (segment st_i, local
+// abscissa st_t) up to the start of segment e, added up in segment order.
+struct ArcCtx {
+    const double *T, *Tseq, *coef, *ftab, *arc_pre;
+    int n, st_i;
+    bool ascending;
+    double st_t, t0, dt;
+};
+
+__device__ double arc_from_origin(const ArcCtx &c, double t1, int *bad)
 {
-    if (t0 > t1) return 0.0;
+    if (c.t0 > t1) return 0.0;
     int en_i;
     double en_t;
-    curve_get_i(T, n, t1, &en_i, &en_t);
-    if (en_t > T[en_i]) en_t = T[en_i];
-    if (st_i == en_i) return quintic_arc_len(coef + 6 * st_i, st_t, en_t, dt, bad);
-    double arc = first_piece;
-    for (int i = st_i + 1; i < en_i; ++i) arc += seg_full[i];
-    arc += quintic_arc_len(coef + 6 * en_i, 0, en_t, dt, bad);
-    return arc;
+    curve_get_i_tab(c.Tseq, c.T, c.n, c.ascending, t1, &en_i, &en_t);
+    if (en_t > c.T[en_i]) en_t = c.T[en_i];
+    if (c.st_i == en_i) return quintic_arc_len(c.coef + 6 * c.st_i, c.st_t, en_t, c.dt, bad);
+    return c.arc_pre[en_i] + quintic_arc_len(c.coef + 6 * en_i, 0, en_t, c.dt, bad, c.ftab + RL_FT * en_i);
 }
 
 // One workgroup per scenario.  Dynamic LDS: tsum[m_max] (double) seg[m_max] (int).
@@ -140,10 +184,14 @@ __global__ void refline_tables_kernel(RlDev a)
     extern __shared__ double smem[];
     __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], seg_full[RL_SEG_CAP];
     __shared__ double vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
+    __shared__ double ftab[RL_SEG_CAP * RL_FT]; // arc-length integrand of every segment at 0, dt, 2dt, ...
+    __shared__ double Tseq[RL_SEG_CAP];         // running sums of T in segment order
+    __shared__ double Scum[RL_SEG_CAP];         // running end of the current segment in calc_point_arr's walk
+    __shared__ double arc_pre[RL_SEG_CAP + 1];  // arc length from the origin to the start of a segment
     __shared__ double red_c[16];
     __shared__ int red_i[16];
     __shared__ double sc_d[8]; // t_max, delta, first piece, s_end
-    __shared__ int sc_i[8];    // M, n, status, k_ori, st_i
+    __shared__ int sc_i[8];    // M, n samples before the appended one, status, k_ori, ascending, parallel walk, start segment
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     double *tsum = smem;
     int *seg = (int *)(smem + a.m_max);
@@ -173,10 +221,30 @@ __global__ void refline_tables_kernel(RlDev a)
     for (int i = tid; i < n; i += nt)
         quintic_coef(ky[i], vv[i], aa[i], ky[i + 1], vv[i + 1], aa[i + 1], T[i], coef + 6 * i);
     __syncthreads();
+    // integrand table: abscissae as get_arange(0, ., dt) places them (0, 0+dt, k*((0+dt)-0))
+    for (int idx = tid; idx < n * RL_FT; idx += nt) {
+        const int i = idx / RL_FT, q = idx - i * RL_FT;
+        const double t = arange_value(q, RL_FT, 0.0, 0.0, dt, (0.0 + dt) - 0.0);
+        const double d = quintic_eval(coef + 6 * i, t, 1);
+        ftab[idx] = __dsqrt_rn(1 + d * d);
+    }
     // projection sample set (curve.py:120-123) and the lagged segment walk of
-    // calc_point_arr (curve.py:43-66), sequential by nature
+    // calc_point_arr (curve.py:43-66): the walk moves on by at most one segment per
+    // sample, when the sample lies more than dt past the running end of the current
+    // one.  With every segment longer than the sample spacing a sample never passes
+    // two ends at once, so the segment of sample j is the start segment plus the
+    // number of ends (+ dt) below it, which every sample finds on its own; shorter
+    // segments take the sequential walk.
     if (tid == 0) {
         int st = MP_RL_OK;
+        double run = 0.0;
+        bool ascending = true, long_segs = true;
+        for (int q = 0; q < n; ++q) {
+            run += T[q];
+            Tseq[q] = run;
+            if (!(T[q] > 0.0)) ascending = false;
+            if (q >= 1 && !(T[q] > dt * (1.0 + 1e-9))) long_segs = false;
+        }
         const double t_max = np_sum_gen(n, [&](int i) { return T[i]; });
         int na;
         double delta;
@@ -186,28 +254,56 @@ __global__ void refline_tables_kernel(RlDev a)
         sc_d[0] = t_max;
         sc_d[1] = delta;
         sc_i[1] = na;
+        const bool parallel_walk = ascending && long_segs;
+        int i0 = 0;
         if (M > 0) {
             // t_arr - t_bios of element 0 is (0 + t_bios) - t_bios
-            int i;
             double tt;
-            curve_get_i(T, n, (0.0 + t_bios) - t_bios, &i, &tt);
-            double t_sum = np_sum_gen(i + 1, [&](int q) { return T[q]; });
-            for (int j = 0; j < M; ++j) {
-                const double tj = (arange_value(j, na, 0.0, t_max, dt, delta) + t_bios) - t_bios;
-                if (tj > t_sum + dt) {
-                    i += 1;
-                    if (i < n) t_sum += T[i];
-                    else { st = MP_RL_E_INDEX; M = 0; break; }
+            curve_get_i(T, n, (0.0 + t_bios) - t_bios, &i0, &tt);
+            double t_sum = np_sum_gen(i0 + 1, [&](int q) { return T[q]; });
+            if (parallel_walk) {
+                Scum[i0] = t_sum;
+                for (int q = i0 + 1; q < n; ++q) { t_sum += T[q]; Scum[q] = t_sum; }
+            } else {
+                int i = i0;
+                for (int j = 0; j < M; ++j) {
+                    const double tj = (arange_value(j, na, 0.0, t_max, dt, delta) + t_bios) - t_bios;
+                    if (tj > t_sum + dt) {
+                        i += 1;
+                        if (i < n) t_sum += T[i];
+                        else { st = MP_RL_E_INDEX; M = 0; break; }
+                    }
+                    seg[j] = i;
+                    tsum[j] = t_sum;
                 }
-                seg[j] = i;
-                tsum[j] = t_sum;
             }
         }
         sc_i[0] = M;
         sc_i[2] = st;
+        sc_i[4] = ascending;
+        sc_i[5] = parallel_walk;
+        sc_i[6] = i0;
     }
     __syncthreads();
     const int M = sc_i[0];
+    const bool ascending = sc_i[4] != 0;
+    {
+        int past_end = 0;
+        if (sc_i[2] == MP_RL_OK && sc_i[5]) {
+            const double t_max_ = sc_d[0], delta_ = sc_d[1];
+            const int na_ = sc_i[1], i0 = sc_i[6];
+            for (int j = tid; j < M; j += nt) {
+                const double tj = (arange_value(j, na_, 0.0, t_max_, dt, delta_) + t_bios) - t_bios;
+                int i = i0;
+                while (i < n && tj > Scum[i] + dt) ++i;
+                if (i < n) { seg[j] = i; tsum[j] = Scum[i]; }
+                else past_end = 1; // the walk would step past the last segment: IndexError
+            }
+        }
+        past_end = __syncthreads_or(past_end);
+        if (past_end && tid == 0) sc_i[2] = MP_RL_E_INDEX;
+        __syncthreads();
+    }
     if (sc_i[2] != MP_RL_OK) {
         if (tid == 0) { a.status[b] = sc_i[2]; a.M[b] = 0; }
         return;
@@ -226,7 +322,7 @@ __global__ void refline_tables_kernel(RlDev a)
         tab_y[k] = y;
         int ii;
         double tt;
-        curve_get_i(T, n, x - t_bios, &ii, &tt);
+        curve_get_i_tab(Tseq, T, n, ascending, x - t_bios, &ii, &tt);
         const double dl = quintic_eval(coef + 6 * ii, tt, 1);
         const double ddl = quintic_eval(coef + 6 * ii, tt, 2);
         tab_th[k] = atan(dl);
@@ -251,19 +347,28 @@ __global__ void refline_tables_kernel(RlDev a)
     const double t0 = rx_ori - t_bios;
     int st_i;
     double st_t;
-    curve_get_i(T, n, t0, &st_i, &st_t);
-    for (int i = tid; i < n; i += nt) seg_full[i] = quintic_arc_len(coef + 6 * i, 0, T[i], dt, &bad);
-    if (tid == 0) sc_d[2] = quintic_arc_len(coef + 6 * st_i, st_t, T[st_i], dt, &bad);
+    curve_get_i_tab(Tseq, T, n, ascending, t0, &st_i, &st_t);
+    for (int i = tid; i < n; i += nt) seg_full[i] = quintic_arc_len(coef + 6 * i, 0, T[i], dt, &bad, ftab + RL_FT * i);
     __syncthreads();
-    const double first_piece = sc_d[2];
+    if (tid == 0) {
+        // arc length up to the start of every later segment, in calc_arc_len's order:
+        // the origin's segment from st_t to its end, then the full segments one by one
+        double arc = quintic_arc_len(coef + 6 * st_i, st_t, T[st_i], dt, &bad);
+        for (int e = st_i + 1; e < n; ++e) {
+            arc_pre[e] = arc;
+            arc += seg_full[e];
+        }
+    }
+    __syncthreads();
+    ArcCtx ac{T, Tseq, coef, ftab, arc_pre, n, st_i, ascending, st_t, t0, dt};
     for (int k = tid; k < M; k += nt) {
         const double x = arange_value(k, na, 0.0, t_max, dt, delta) + t_bios;
-        tab_s[k] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, x - t_bios, dt, &bad);
+        tab_s[k] = arc_from_origin(ac, x - t_bios, &bad);
     }
     // get_s of the last knot: the length SLMap lays its layers along (sl_map.py:52)
     const double rx_max = kx[n];
     if (tid == 0)
-        sc_d[3] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, rx_max - t_bios, dt, &bad);
+        sc_d[3] = arc_from_origin(ac, rx_max - t_bios, &bad);
     // Frenet->Cartesian table (cfc.py:55-60, 72-86): abscissae
     // get_arange(rx_ori, rx_max, d_x) with their arc length, ordinate and heading
     int n_inv = 0;
@@ -276,10 +381,10 @@ __global__ void refline_tables_kernel(RlDev a)
             const double x = arange_value(k, ng, rx_ori, rx_max, dt, dg);
             int ii;
             double tt;
-            curve_get_i(T, n, x - t_bios, &ii, &tt);
+            curve_get_i_tab(Tseq, T, n, ascending, x - t_bios, &ii, &tt);
             const size_t o = (size_t)b * a.m_max + k;
             a.inv_x[o] = x;
-            a.inv_s[o] = arc_from_origin(T, n, coef, seg_full, first_piece, st_i, st_t, t0, x - t_bios, dt, &bad);
+            a.inv_s[o] = arc_from_origin(ac, x - t_bios, &bad);
             a.inv_y[o] = quintic_eval(coef + 6 * ii, tt, 0);
             a.inv_theta[o] = atan(quintic_eval(coef + 6 * ii, tt, 1));
         }
@@ -501,7 +606,9 @@ extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double 
             tab_kappa, M, origin, status, inv_x, inv_s, inv_y, inv_theta, n_inv};
     size_t lds = (size_t)m_max * (sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(m_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    int threads = m_max <= 128 ? 128 : 256;
+    if (const char *t_env = getenv("MP_RL_THREADS")) threads = atoi(t_env); // development aid
+    hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_refline_tables");
 }
 

@@ -112,6 +112,51 @@ def test_c2f_random_vs_oracle(oracle):
             close(sd[q], want[2], rtol=1e-10)
 
 
+def test_refline_irregular_knot_spacing_vs_oracle(oracle):
+    """Knot spacings the default waypoints never have: segments shorter than the sample
+    spacing (the lagged segment walk must then run sequentially), segments of 9-12 m
+    (more samples per segment than the integrand table holds), a mix of both, and the
+    regular 4.5 m line for reference.  Tables and the Frenet->Cartesian table against the
+    oracle's Curve / CartesianFrenetConverter."""
+    import torch
+    rng = np.random.default_rng(11)
+    gaps = [np.array([4.5, 0.3, 4.5, 0.45, 0.2, 5.0, 3.0, 0.4, 6.0, 4.5, 4.5]),
+            np.array([9.0, 12.0, 10.5, 9.5, 8.2]),
+            np.array([2.0, 11.0, 0.35, 7.0, 0.6, 0.6, 9.0, 1.0, 3.3]),
+            np.full(14, 4.5),
+            rng.uniform(0.6, 7.0, 15)]
+    lines, egos = [], []
+    for k, g in enumerate(gaps):
+        xs = -2.0 + np.concatenate([[0.0], np.cumsum(g)])
+        lines.append((xs, 0.004 * (k - 2) * xs * xs + 0.3 * np.sin(xs / 9.0)))
+        egos.append([rng.uniform(-1, 3), rng.uniform(-0.5, 0.5)])
+    egos = np.array(egos)
+    t = build_tables(lines, egos)
+    torch.cuda.synchronize()
+    for b, (rx, ry) in enumerate(lines):
+        try:
+            conv = oracle.CartesianFrenetConverter(egos[b, 0], egos[b, 1], rx, ry, 0.0)
+        except IndexError:
+            assert int(t.status[b]) == -1, b   # MP_RL_E_INDEX
+            continue
+        assert int(t.status[b]) == 1, b
+        tx, xx, S, th, kr = conv.tables()
+        M = int(t.M[b])
+        assert M == len(tx)
+        assert np.array_equal(t.tab_x[b, :M].cpu().numpy(), tx)
+        close(t.tab_y[b, :M].cpu().numpy(), xx)
+        close(t.tab_s[b, :M].cpu().numpy(), S)
+        close(t.tab_theta[b, :M].cpu().numpy(), th)
+        close(t.tab_kappa[b, :M].cpu().numpy(), kr, rtol=1e-10)
+        close(t.origin[b, :2].cpu().numpy(), [conv.rx_ori, conv.ry_ori])
+        close(float(t.origin[b, 2]), conv.get_s(rx[-1]))
+        # Frenet -> Cartesian table: get_rxy at a few arc lengths
+        for sq in np.linspace(0.0, float(t.origin[b, 2]), 7):
+            from motion_planning_amd import batch as mb
+            x, y = mb.f2c(t, np.array([sq]), np.array([0.4]), np.array([b]))
+            close([float(x[0]), float(y[0])], conv.frenet_to_cartesian(sq, 0.4), rtol=1e-10)
+
+
 def test_refline_capacity_status():
     import torch
     from motion_planning_amd import batch as mb, _lib
