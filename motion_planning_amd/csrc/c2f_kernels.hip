@@ -495,7 +495,9 @@ __global__ void curve_eval_kernel(CvDev a)
 {
     extern __shared__ double smem[];
     __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
-    __shared__ int sc_i[4]; // n samples, status
+    __shared__ double Scum[RL_SEG_CAP]; // running end of the current segment in calc_point_arr's walk
+    __shared__ double sc_d[2];          // fill step and end of the sample set
+    __shared__ int sc_i[4];             // n samples, status, start segment / samples on the grid, ascending
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     double *tq = smem, *tsum = smem + a.q_max;
     int *seg = (int *)(smem + 2 * (size_t)a.q_max);
@@ -518,42 +520,102 @@ __global__ void curve_eval_kernel(CvDev a)
     for (int i = tid; i < n; i += nt)
         quintic_coef(kx[i], vv[i], aa[i], kx[i + 1], vv[i + 1], aa[i + 1], T[i], coef + 6 * i);
     __syncthreads();
+    // sample abscissae
     if (tid == 0) {
-        int st = MP_RL_OK, m = 0;
+        int st = MP_RL_OK, m = 0, na = 0;
+        double delta = 0.0, t_en = 0.0;
         if (a.mode == 2) {
             m = a.n_query[b];
             if (m > a.q_max) { st = MP_RL_E_CAPACITY; m = 0; }
-            for (int j = 0; j < m; ++j) tq[j] = a.query[(size_t)b * a.q_max + j];
         } else {
-            const double t_en = (a.mode == 0) ? t_bios + np_sum_gen(n, [&](int i) { return T[i]; }) : kt[n];
-            int na;
-            double delta;
+            t_en = (a.mode == 0) ? t_bios + np_sum_gen(n, [&](int i) { return T[i]; }) : kt[n];
             m = arange_count(t_bios, t_en, dt, a.q_max, &na, &delta);
             if (m < 0) { st = MP_RL_E_CAPACITY; m = 0; }
-            for (int j = 0; j < m; ++j) tq[j] = arange_value(j, na, t_bios, t_en, dt, delta);
         }
         if (st == MP_RL_OK && m == 0) st = MP_RL_E_INDEX; // t_arr[0] of an empty array
-        if (m > 0) {
-            const double first = tq[0] - t_bios;
-            if (first < 0.0) { st = MP_RL_E_INDEX; m = 0; }
-            else {
-                int i;
-                double tt;
-                curve_get_i(T, n, first, &i, &tt);
-                double t_sum = np_sum_gen(i + 1, [&](int q) { return T[q]; });
-                for (int j = 0; j < m; ++j) {
-                    if (tq[j] - t_bios > t_sum + dt) {
-                        i += 1;
-                        if (i < n) t_sum += T[i];
-                        else { st = MP_RL_E_INDEX; m = 0; break; }
-                    }
-                    seg[j] = i;
-                    tsum[j] = t_sum;
-                }
+        sc_i[0] = m;
+        sc_i[1] = st;
+        sc_i[2] = na;
+        sc_d[0] = delta;
+        sc_d[1] = t_en;
+    }
+    __syncthreads();
+    {
+        const int m0 = sc_i[0], na = sc_i[2];
+        const double delta = sc_d[0], t_en = sc_d[1];
+        for (int j = tid; j < m0; j += nt)
+            tq[j] = (a.mode == 2) ? a.query[(size_t)b * a.q_max + j] : arange_value(j, na, t_bios, t_en, dt, delta);
+    }
+    __syncthreads();
+    // calc_point_arr's walk over the segments (curve.py:43-66): it moves on by at most one
+    // segment per sample, when the sample lies more than dt past the running end of the
+    // current one.  Every sample first counts the segment ends (+ dt) below it on its own;
+    // if those counts never drop and never rise by more than one from sample to sample they
+    // ARE the walk's segments, otherwise the walk is done sequentially.
+    if (tid == 0 && sc_i[0] > 0) {
+        int st = sc_i[1], m = sc_i[0], i0 = 0;
+        const double first = tq[0] - t_bios;
+        bool ascending = true;
+        if (first < 0.0) { st = MP_RL_E_INDEX; m = 0; }
+        else {
+            double tt;
+            curve_get_i(T, n, first, &i0, &tt);
+            double t_sum = np_sum_gen(i0 + 1, [&](int q) { return T[q]; });
+            Scum[i0] = t_sum;
+            for (int q = i0 + 1; q < n; ++q) {
+                t_sum += T[q];
+                Scum[q] = t_sum;
+                if (!(T[q] > 0.0)) ascending = false;
             }
         }
         sc_i[0] = m;
         sc_i[1] = st;
+        sc_i[2] = i0;
+        sc_i[3] = ascending;
+    }
+    __syncthreads();
+    {
+        const int m0 = sc_i[0], i0 = sc_i[2];
+        int irregular = sc_i[3] ? 0 : 1;
+        if (!irregular) {
+            for (int j = tid; j < m0; j += nt) {
+                const double tj = tq[j] - t_bios;
+                int i = i0;
+                while (i < n && tj > Scum[i] + dt) ++i;
+                seg[j] = i;
+            }
+        }
+        __syncthreads();
+        if (!irregular) {
+            for (int j = tid; j < m0; j += nt) {
+                const int step = seg[j] - (j > 0 ? seg[j - 1] : i0);
+                if (step < 0 || step > 1) irregular = 1;
+            }
+        }
+        irregular = __syncthreads_or(irregular);
+        if (!irregular) {
+            int past_end = 0;
+            for (int j = tid; j < m0; j += nt) {
+                if (seg[j] < n) tsum[j] = Scum[seg[j]];
+                else past_end = 1; // the walk steps past the last segment: IndexError
+            }
+            past_end = __syncthreads_or(past_end);
+            if (past_end && tid == 0) { sc_i[0] = 0; sc_i[1] = MP_RL_E_INDEX; }
+        } else if (tid == 0 && m0 > 0) {
+            int i = i0, m = m0, st = sc_i[1];
+            double t_sum = np_sum_gen(i + 1, [&](int q) { return T[q]; });
+            for (int j = 0; j < m; ++j) {
+                if (tq[j] - t_bios > t_sum + dt) {
+                    i += 1;
+                    if (i < n) t_sum += T[i];
+                    else { st = MP_RL_E_INDEX; m = 0; break; }
+                }
+                seg[j] = i;
+                tsum[j] = t_sum;
+            }
+            sc_i[0] = m;
+            sc_i[1] = st;
+        }
     }
     __syncthreads();
     const int m = sc_i[0];

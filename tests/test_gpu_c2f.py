@@ -240,3 +240,54 @@ def test_curve_eval_golden():
                 close(r["t"][b, :len(tt)].cpu().numpy(), tt)
                 close(r["x"][b, :len(tt)].cpu().numpy(), g["cv%d_arr" % i][0])
                 close(r["dx"][b, :len(tt)].cpu().numpy(), g["cv%d_arr" % i][1])
+
+
+def test_curve_eval_irregular_walks_vs_oracle(oracle):
+    """calc_point_arr's segment walk in the cases the planner's own curves never produce:
+    knots closer than the sample spacing (the walk lags behind), query abscissae that jump
+    over several segments, go backwards or run past the last knot (IndexError), next to
+    regular ones.  Values and first derivatives against the oracle's Curve."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(23)
+    dt = 0.5
+    knot_sets = [np.concatenate([[0.0], np.cumsum(g)]) + 1.5 for g in (
+        np.array([4.0, 0.3, 0.2, 4.0, 0.4, 5.0, 3.0]), np.full(9, 8.0), rng.uniform(0.2, 3.0, 20),
+        np.array([2.0, 2.0, 2.0, 2.0]), np.full(6, 1.0))]
+    B = len(knot_sets)
+    nk = max(len(k) for k in knot_sets)
+    q_max = 160
+    kt, kx = np.zeros((B, nk)), np.zeros((B, nk))
+    n_k = np.array([len(k) for k in knot_sets], np.int32)
+    vec = rng.uniform(-0.2, 0.2, B)
+    for b, k in enumerate(knot_sets):
+        kt[b, :len(k)] = k
+        kx[b, :len(k)] = np.sin(k / 3.0) + 0.1 * rng.standard_normal(len(k))
+    queries = [np.sort(rng.uniform(knot_sets[0][0], knot_sets[0][-1], 40)),          # ascending, short segments
+               np.array([1.5, 2.0, 30.0, 31.0, 60.0, 70.0]),                          # jumps over segments
+               np.sort(rng.uniform(knot_sets[2][0], knot_sets[2][-1], 100)),          # dense, ragged knots
+               np.array([1.5, 4.0, 3.0, 8.0, 9.4]),                                   # goes backwards
+               np.array([1.5, 3.0, 5.0, 7.4, 9.0, 14.0, 15.0, 16.0])]                 # past the last knot
+    query, n_q = np.zeros((B, q_max)), np.zeros(B, np.int32)
+    for b, q in enumerate(queries):
+        n_q[b] = len(q)
+        query[b, :len(q)] = q
+    arc = mb.curve_eval(kt, kx, n_k, vec, dt, mb.CURVE_ARC, q_max, want_dx=True)
+    qry = mb.curve_eval(kt, kx, n_k, vec, dt, mb.CURVE_QUERY, q_max, query=query, n_query=n_q, want_dx=True)
+    torch.cuda.synchronize()
+    n_err = 0
+    for b, k in enumerate(knot_sets):
+        cv = oracle.Curve(k, dt, kx[b, :len(k)], vec[b])
+        tt_arc = oracle.get_arange(k[0], k[0] + oracle.np_sum(np.diff(k)), dt)
+        for r, tt in ((arc, tt_arc), (qry, queries[b])):
+            try:
+                want = cv.calc_point_arr(tt, 0), cv.calc_point_arr(tt, 1)
+            except IndexError:
+                assert int(r["status"][b]) == -1 and int(r["n"][b]) == 0, b
+                n_err += 1
+                continue
+            assert int(r["status"][b]) == 1 and int(r["n"][b]) == len(tt), b
+            close(r["t"][b, :len(tt)].cpu().numpy(), tt)
+            close(r["x"][b, :len(tt)].cpu().numpy(), want[0], rtol=1e-10)
+            close(r["dx"][b, :len(tt)].cpu().numpy(), want[1], rtol=1e-10)
+    assert n_err >= 1
