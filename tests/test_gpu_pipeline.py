@@ -174,3 +174,47 @@ def test_pipeline_map_too_big_is_a_status():
     r = pl.plan_batch(**pack_scenes([ok, big]))
     torch.cuda.synchronize()
     assert list(r["status"].cpu().numpy()) == [pl.PIPE_OK, pl.PIPE_MAP_TOO_BIG]
+
+
+def test_plan_scenes_replays_as_a_hip_graph():
+    """mp_plan_scenes only enqueues work on the caller's stream (no allocation, no
+    synchronisation, nothing read back), so a caller can capture it in a HIP graph and
+    replay it on new inputs written into the same buffers."""
+    import torch
+    from motion_planning_amd import batch as mb, pipeline as pl
+    rng = np.random.default_rng(4)
+    packs = [pack_scenes([random_scene(rng, 12, 3) for _ in range(5)]) for _ in range(2)]
+    nk = max(p["knots_x"].shape[1] for p in packs)
+
+    def dev_scenes(p):
+        B = p["knots_x"].shape[0]
+        kx, ky = np.zeros((B, nk)), np.zeros((B, nk))
+        kx[:, :p["knots_x"].shape[1]], ky[:, :p["knots_y"].shape[1]] = p["knots_x"], p["knots_y"]
+        d = dict(knots_x=mb.to_dev(kx), knots_y=mb.to_dev(ky), n_knots=mb.to_dev(p["n_knots"], torch.int32),
+                 ego_vel=mb.to_dev(p["ego_vel"]), st_pos=mb.to_dev(p["st_pos"]), st_rad=mb.to_dev(p["st_rad"]),
+                 n_st=mb.to_dev(p["n_st"], torch.int32), dy_pos=mb.to_dev(p["dy_pos"]),
+                 dy_rad=mb.to_dev(p["dy_rad"]), n_dy=mb.to_dev(p["n_dy"], torch.int32),
+                 line_vec=torch.zeros(B, dtype=torch.float64, device="cuda"))
+        return d
+
+    params = pl.default_params()
+    dims = pl.plan_dims(5, nk, 12, 3, m_max=232, params=params)
+    eager = []
+    for p in packs:
+        a = pl.plan_scenes(dev_scenes(p), dims, params)
+        torch.cuda.synchronize()
+        eager.append({k: v.clone() for k, v in a.arrays.items() if k in ("status", "path_idx", "vv", "final_x", "final_y")})
+    buf = dev_scenes(packs[0])
+    arena = pl.PlanArena(dims)
+    pl.plan_scenes(buf, dims, params, arena)        # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pl.plan_scenes(buf, dims, params, arena)
+    for p, want in zip(packs, eager):
+        for k, v in dev_scenes(p).items():
+            buf[k].copy_(v)
+        g.replay()
+        torch.cuda.synchronize()
+        for k, v in want.items():
+            assert torch.equal(arena.arrays[k], v), k
