@@ -713,7 +713,11 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
     const char *th_env = getenv("MP_ST_THREADS");
-    int threads = th_env ? atoi(th_env) : (n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256));
+    int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
+    // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
+    // wide grid gets more lanes per layer
+    if (B <= 512 && n_s_max > 64) threads = 512;
+    if (th_env) threads = atoi(th_env);
     size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     hipLaunchKernelGGL(st_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
