@@ -1,7 +1,10 @@
 """Ad-hoc timing of the ST DP kernel under different shapes (development aid)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
-from motion_planning_amd import batch as mb
+from motion_planning_amd import batch as mb, _lib
+import os
+if os.environ.get('MP_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['MP_LIB_PATH']   # A/B timing against another build
 import bench
 
 def run(B, n_s, R, label):
