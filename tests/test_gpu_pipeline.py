@@ -218,3 +218,72 @@ def test_plan_scenes_replays_as_a_hip_graph():
         torch.cuda.synchronize()
         for k, v in want.items():
             assert torch.equal(arena.arrays[k], v), k
+
+
+def test_pipeline_full_size_batch_properties_and_sample_vs_oracle(oracle):
+    """The benchmark's whole-replan workload (4096 scenes, 192 static + 64 moving obstacles
+    each, curved lines): two runs agree bit for bit, every status is one the reference
+    can produce, per-scene invariants hold for all scenes, and a sample of scenes of every
+    outcome matches the oracle's chain end to end."""
+    import torch
+    import bench
+    from motion_planning_amd import batch as mb, pipeline as pl
+    B = 4096
+    sc = bench.make_scenes(B)
+    dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
+    dev["line_vec"] = torch.zeros(B, dtype=torch.float64, device="cuda")
+    params = pl.default_params()
+    dims = pl.plan_dims(B, sc["knots_x"].shape[1], 192, 64, n_l=5, m_max=200, params=params)
+    a1 = pl.plan_scenes(dev, dims, params)
+    a2 = pl.plan_scenes(dev, dims, params)
+    torch.cuda.synchronize()
+    r = a1.arrays
+    for k in ("status", "path_idx", "n_ob", "ob_s", "st_n_reg", "st_path_s_ind", "ss", "vv", "final_x", "final_y"):
+        assert torch.equal(r[k], a2.arrays[k]), k
+    status = r["status"].cpu().numpy()
+    assert set(np.unique(status)) <= {pl.PIPE_OK, pl.PIPE_NOT_FOUND, pl.PIPE_MAP_TOO_BIG}
+    assert (status == pl.PIPE_OK).mean() > 0.3 and (status == pl.PIPE_NOT_FOUND).any()
+    n_layers = r["n_layers"].cpu().numpy()
+    path_idx = r["path_idx"].cpu().numpy()
+    n_prof, plen = r["n_prof"].cpu().numpy(), r["st_path_len"].cpu().numpy()
+    st_idx = r["st_path_s_ind"].cpu().numpy()
+    vv, ss = r["vv"].cpu().numpy(), r["ss"].cpu().numpy()
+    ok = status == pl.PIPE_OK
+    assert (n_layers[status == pl.PIPE_MAP_TOO_BIG] == 0).all() and (n_layers[ok] >= 2).all()
+    assert (n_prof[~ok] == 0).all() and (n_prof[ok] == (plen[ok] - 1) * 5 + 1).all()
+    for b in np.flatnonzero(ok):
+        n = n_layers[b]
+        assert (path_idx[b, :n] >= 0).all() and (path_idx[b, :n] < 5).all() and (path_idx[b, n:] == -1).all()
+        p = st_idx[b, :plen[b]]
+        assert p[0] == 0 and (np.diff(p) >= 0).all()              # s never decreases along the speed plan
+    assert np.allclose(vv[ok, 0], r["robot_vel"].cpu().numpy()[ok])  # the profile starts at the ego's speed
+    assert (ss[ok, 0] == 0.0).all()
+    sample = (list(np.flatnonzero(ok)[:10]) + list(np.flatnonzero(status == pl.PIPE_NOT_FOUND)[:5]) +
+              list(np.flatnonzero(status == pl.PIPE_MAP_TOO_BIG)[:3]))
+    for b in sample:
+        nk = int(sc["n_knots"][b])
+        st = [(p, rad) for p, rad in zip(sc["st_pos"][b], sc["st_rad"][b])]
+        dy = [(fr, rad) for fr, rad in zip(sc["dy_pos"][b], sc["dy_rad"][b])]
+        try:
+            sl = oracle.SLMap(sc["knots_x"][b, :nk], sc["knots_y"][b, :nk], 0.0, sc["ego_vel"][b], st, dy)
+        except ValueError:
+            assert status[b] == pl.PIPE_MAP_TOO_BIG
+            continue
+        assert n_layers[b] == sl.n_s and int(r["n_ob"][b]) == len(sl.ob_list)
+        found, curve, ref = oracle.sl_plan(sl)
+        assert (status[b] == pl.PIPE_OK) == found
+        if not found:
+            continue
+        assert np.array_equal(path_idx[b, :sl.n_s], ref["path_idx"])
+        pb = sl.path_sampling(curve)
+        n_s, n_t = oracle.st_dims(pb[-1][0])
+        down, up, n_reg = oracle.st_add_obstacle(n_t, pb, sl.st_ob_traj, sl.dy_ob_traj)
+        assert np.array_equal(r["st_n_reg"][b].cpu().numpy(), n_reg)
+        sr = oracle.st_find_speed(n_t, n_s, down, up, n_reg, sl.robot_vel, 25.0 * 5.0 / 18.0)
+        assert np.array_equal(st_idx[b, :plen[b]], sr["path_s_ind"])
+        want_ss, want_vv = oracle.speed_profile(sr["path_s_ind"], sl.robot_vel)
+        n = int(n_prof[b])
+        assert n == len(want_ss)
+        close(vv[b, :n], want_vv, rtol=1e-10)
+        close(np.stack([r["final_x"][b, :n].cpu().numpy(), r["final_y"][b, :n].cpu().numpy()], 1),
+              sl.path_convert(sl.path_sampling(curve, want_ss)), rtol=1e-10)
