@@ -364,7 +364,12 @@ struct PairStore {
     // layer alone exceeds the store: its pairs must then be found another way.
     __device__ __forceinline__ int layer_pairs(int s, int *off_out, bool *stored) const
     {
-        int n = cntL[s], off = offL[s];
+        return layer_pairs(s, cntL[s], offL[s], off_out, stored);
+    }
+
+    // The same with cntL[s] / offL[s] already read by the caller (a layer ahead).
+    __device__ __forceinline__ int layer_pairs(int s, int n, int off, int *off_out, bool *stored) const
+    {
         if (off != PAIRS_TOO_MANY && off + n > cap) {
             __syncthreads();
             place(s);
@@ -601,6 +606,27 @@ __global__ void sl_plan_kernel(SlDev a)
     double l_cur = is_target ? lbase[tid] : 0.0; // row 0, this thread's node
     int status = MP_SL_FOUND;
     int done = 0;
+    // Everything a layer needs that was fixed by the prologue is read one layer ahead,
+    // before the barrier that ends the layer in front of it, so that the LDS round trips
+    // overlap with that layer's reduction and barrier instead of starting the next one.
+    struct LayerRegs {
+        int kn, n_pairs, pair_off;
+        bool sorted;
+        double p2s, Q, w_inv, A, mid;
+    } cur, nxt;
+    auto load_layer = [&](int s, LayerRegs &L) {
+        L.kn = layK[s];
+        L.n_pairs = cntL[s];
+        L.pair_off = offL[s];
+        L.sorted = s == 0 || laySorted[rstride ? s - 1 : 0] != 0;
+        L.p2s = layP2[s];
+        L.Q = layQ[s];
+        L.w_inv = layW[s];
+        L.A = layA[s];
+        L.mid = layMid[s == 0 ? n_s - 1 : s - 1]; // layer 0: the last row's centre, as index -1 picks it
+    };
+    load_layer(0, cur);
+    double p1s = ego_s;
     for (int s = 0; s < n_s; ++s) {
         const int buf = s & 1;
         double m_prev = 0.0; // minimum accumulated cost over the previous layer
@@ -612,23 +638,25 @@ __global__ void sl_plan_kernel(SlDev a)
                 if (a.p.early_exit) break;
             }
         }
-        const LayerGeom geo = layer_geo(s);
+        LayerGeom geo;
+        geo.K = cur.kn < 0 ? cur.kn : (cur.kn & 0xffff);
+        geo.n = cur.kn < 0 ? 0 : geo.K - (cur.kn >> 16);
+        geo.delta = (p1s + d_s) - p1s;
         if (geo.K < 0) { status = geo.K; break; }
         const int n_src = (s == 0) ? 1 : n_l;
         int ent_off;
         bool ent_stored;
-        const int n_ent = ps.layer_pairs(s, &ent_off, &ent_stored);
+        const int n_ent = ps.layer_pairs(s, cur.n_pairs, cur.pair_off, &ent_off, &ent_stored);
         // next row of the lateral grid, in flight while this layer is relaxed
         double l_next = l_cur;
         if (rstride && is_target && s + 1 < n_s) l_next = lbase[(size_t)(s + 1) * rstride + tid];
-        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
-        const double p2s = layP2[s];
-        const double Q = layQ[s], w_inv = layW[s];
-        const bool sorted = s == 0 || laySorted[rstride ? s - 1 : 0] != 0;
+        const double p2s = cur.p2s;
+        const double Q = cur.Q, w_inv = cur.w_inv;
+        const bool sorted = cur.sorted;
         SrcSh src;
         src.lc = lc_all + buf * n_lp;
-        src.mid = layMid[s == 0 ? n_s - 1 : s - 1]; // layer 0: the last row's centre, as index -1 picks it
-        src.two_cga = 2.0 * cG * layA[s];
+        src.mid = cur.mid;
+        src.two_cga = 2.0 * cG * cur.A;
         src.K = geo.K;
         src.w_d = w_d;
         src.d_s = d_s;
@@ -663,10 +691,13 @@ __global__ void sl_plan_kernel(SlDev a)
             lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
         }
         done = s + 1;
+        if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
         best = wave_min_f64(best);
         if ((tid & (MP_WAVE - 1)) == 0) red[(buf ^ 1) * 8 + wave] = best;
         __syncthreads();
         l_cur = l_next;
+        p1s = p2s;
+        cur = nxt;
     }
     if (done == n_s && n_s >= 2 && status == MP_SL_FOUND) {
         // the last layer's abort test
