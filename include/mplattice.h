@@ -17,6 +17,14 @@
  *     errors detected on the host (nothing was enqueued); per-scenario outcomes
  *     are written to the `status` array on the device;
  *   - all real numbers are IEEE double, indices are int32.
+ *
+ * Testing aids read from the environment at launch time (they select between
+ * code paths that must give identical results, or tune a launch; unset = the
+ * normal choice): MP_SL_NARROW=0 (lattices of up to 16 lanes through the
+ * thread-per-node kernel), MP_SL_PAIR_CAP=n (size of the kernels' LDS pair
+ * store), MP_ST_REGIONS_ONCE=0 (per-layer scans in mp_st_regions),
+ * MP_ST_THREADS=n / MP_RL_THREADS=n (workgroup size of mp_st_dp /
+ * mp_refline_tables).
  */
 #ifndef MPLATTICE_H
 #define MPLATTICE_H
@@ -325,7 +333,10 @@ int mp_plan_array_info(const mp_plan_dims *dims, int32_t i, const char **name, i
                        int64_t shape[4], int64_t *offset);
 int64_t mp_plan_arena_bytes(const mp_plan_dims *dims);
 /* Enqueues the whole chain on `stream`.  arena: device memory of at least
- * mp_plan_arena_bytes(dims) bytes, 256-byte aligned. */
+ * mp_plan_arena_bytes(dims) bytes, 256-byte aligned.  Argument errors are found
+ * before anything is enqueued; a launch failure part-way (MP_E_LAUNCH) leaves
+ * the earlier stages enqueued and the arena's later arrays undefined.  The call
+ * can be captured in a HIP graph. */
 int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                    void *arena, int64_t arena_bytes, void *stream);
 

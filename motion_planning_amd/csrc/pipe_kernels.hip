@@ -277,7 +277,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
         a.o.ego_sl[2 * b + 1] = l;
         a.o.robot_vel[b] = c2f_s_dt(tth[k], a.o.tab_kappa[tb + k], l, a.in.ego_vel[2 * b], a.in.ego_vel[2 * b + 1]);
     }
-    if (tid == MP_WAVE % nt) {
+    if (tid == (nt > MP_WAVE ? MP_WAVE : 0)) { // first lane of the second wave, if there is one
         // layers every layer_gap, the line's end as the last one (sl_map.py:53-66)
         double *lay = a.o.s_layers + (size_t)b * d.n_s_max;
         double ss = a.layer_gap;
