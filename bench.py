@@ -128,6 +128,49 @@ def cpu_pipeline(sc, n_sample, threads):
     return n_sample / dt, dt
 
 
+class ResultGather:
+    """The per-step exchange of result records when more than one GPU takes part: pack on
+    the device (one kernel), then one all-gather issued asynchronously on the process
+    group's own stream into one of two buffer pairs, so that the exchange of batch k runs
+    while the kernels of batch k+1 do; a buffer pair is waited for before it is reused,
+    and drain() waits for everything (called before the clock stops)."""
+
+    def __init__(self, world, backend, B, n_s, n_t):
+        import torch
+        from motion_planning_amd import dist as mdist
+        self.world, self.backend, self.mdist = world, backend, mdist
+        self.k = 0
+        if world == 1:
+            return
+        width = mdist.record_width(n_s, n_t)
+        gdev = "cuda" if backend == "nccl" else "cpu"
+        self.packed = [torch.empty((B, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.gathered = [torch.empty((world * B, width), dtype=torch.uint8, device=gdev) for _ in range(2)]
+        self.pending = [None, None]
+
+    def submit(self, path_idx, status, layers_done, best_cost, st_path, st_len):
+        if self.world == 1:
+            return
+        i = self.k & 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()
+        self.mdist.pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=self.packed[i])
+        src = self.packed[i] if self.backend == "nccl" else self.packed[i].cpu()
+        self.pending[i] = self.mdist.gather_results_same_size(src, self.gathered[i], async_op=True)
+        self.k += 1
+
+    def drain(self):
+        if self.world == 1:
+            return
+        for i in range(2):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+    def last(self):
+        return self.gathered[(self.k - 1) & 1]
+
+
 def bench_pipeline(args, world, rank, backend):
     """--workload pipeline: one step = one mp_plan_scenes call over B scenes resident in
     HBM (every stage of the replan) and, with more than one GPU, the result gather."""
@@ -144,17 +187,12 @@ def bench_pipeline(args, world, rank, backend):
                         params=params)
     arena = pl.PlanArena(dims)
     a = arena.arrays
-    row = mdist.record_width(dims.n_s_max, dims.n_t)
-    packed = torch.empty((B, row), dtype=torch.int32, device="cuda")
-    gdev = "cuda" if backend == "nccl" else "cpu"
-    gathered = torch.empty((world * B, row), dtype=torch.int32, device=gdev) if world > 1 else None
+    gather = ResultGather(world, backend, B, dims.n_s_max, dims.n_t)
 
     def step():
         pl.plan_scenes(dev, dims, params, arena)
-        if world > 1:
-            mdist.pack_results(a["path_idx"], a["sl_status"], a["layers_done"], a["best_cost"], a["st_path_s_ind"],
-                               a["st_path_len"], out=packed)
-            mdist.gather_results_same_size(packed if backend == "nccl" else packed.cpu(), gathered)
+        gather.submit(a["path_idx"], a["sl_status"], a["layers_done"], a["best_cost"], a["st_path_s_ind"],
+                      a["st_path_len"])
 
     def fence():
         torch.cuda.synchronize()
@@ -164,16 +202,20 @@ def bench_pipeline(args, world, rank, backend):
 
     for _ in range(args.warmup):
         step()
+    gather.drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    gather.drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        u = mdist.unpack_results(gather.last()[rank * B:(rank + 1) * B].to("cuda"), dims.n_s_max, dims.n_t)
+        assert torch.equal(u["path_idx"], a["path_idx"]) and torch.equal(u["st_path"], a["st_path_s_ind"])
     status = a["status"].cpu().numpy()
     assert set(np.unique(status)) <= {1, 0, -4}, "unexpected scene status %s" % np.unique(status)
     n_prof = a["n_prof"].cpu().numpy()
@@ -303,10 +345,7 @@ def main():
     out = mb.SLPlanOut(B, N_S, N_L, want_maps=bool(args.maps))
     st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
                  n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
-    row = mdist.record_width(N_S, ST_N_T)  # int32 words per scenario in the gathered record
-    packed = torch.empty((B, row), dtype=torch.int32, device="cuda")
-    gdev = "cuda" if backend == "nccl" else "cpu"
-    gathered = torch.empty((world * B, row), dtype=torch.int32, device=gdev) if world > 1 else None
+    gather = ResultGather(world, backend, B, N_S, ST_N_T)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -321,10 +360,7 @@ def main():
                       want_tables=bool(args.maps), n_s_max=ST_N_S)
         if i is not None:
             ev[i][2].record()
-        if world > 1:
-            mdist.pack_results(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"],
-                               st["path_len"], out=packed)
-            mdist.gather_results_same_size(packed if backend == "nccl" else packed.cpu(), gathered)
+        gather.submit(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"], st["path_len"])
         return st
 
     def fence():
@@ -335,10 +371,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gather.drain()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         st = step(i)
+    gather.drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -357,8 +395,10 @@ def main():
 
     if world > 1:
         # every rank holds every scenario's record, in scenario order
+        gathered = gather.last()
         u = mdist.unpack_results(gathered[rank * B:(rank + 1) * B].to("cuda"), N_S, ST_N_T)
         assert torch.equal(u["path_idx"], out.path_idx) and torch.equal(u["st_path"], st["path_s_ind"])
+        assert torch.equal(u["status"], out.status) and torch.equal(u["best_cost"].isnan(), out.best_cost.isnan())
         assert int((mdist.unpack_results(gathered, N_S, ST_N_T)["st_len"] >= 2).sum()) == world * B
     if rank == 0:
         plans_per_s = world * B * args.steps / elapsed

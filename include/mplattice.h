@@ -245,6 +245,20 @@ int mp_robot_to_world(int32_t n_pts, const double *x, const double *y, const int
                       const double *rot, const double *trans, double *wx, double *wy, void *stream);
 
 
+/* ---- result record for the gather across GPUs ------------------------------
+ * No counterpart in the reference (it plans one scene in one process): ranks
+ * plan disjoint blocks of scenarios and exchange one fixed-size record per
+ * scenario.  Record of mp_result_record_bytes(n_s, n_t) bytes, little endian:
+ *   [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
+ *   | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1; lattices of up to 255 lanes)
+ *   | zero padding to a multiple of 8
+ * mp_pack_results writes records [B][record bytes] from the outputs of
+ * mp_sl_plan and mp_st_dp (best_cost may be NULL: 0.0). */
+int32_t mp_result_record_bytes(int32_t n_s, int32_t n_t);
+int mp_pack_results(int32_t B, int32_t n_s, int32_t n_t, const int32_t *path_idx, const int32_t *status,
+                    const int32_t *layers_done, const double *best_cost, const int32_t *st_path,
+                    const int32_t *st_len, void *records, void *stream);
+
 /* ---- whole replan, B scenes per call --------------------------------------
  * Replaces what PlannerInterface.run_step computes between coor_trans and the
  * conversion back to the world frame (Planning/Interface/planner_interface.py:

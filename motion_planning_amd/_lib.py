@@ -73,6 +73,8 @@ SIGNATURES = {
                                                                                          C.c_int32, C.c_double]
                         + [_vp] * 12),
     "mp_robot_to_world": (C.c_int, [C.c_int32] + [_vp] * 8),
+    "mp_result_record_bytes": (C.c_int32, [C.c_int32, C.c_int32]),
+    "mp_pack_results": (C.c_int, [C.c_int32] * 3 + [_vp] * 8),
     "mp_plan_default_params": (None, [C.POINTER(PlanParams)]),
     "mp_plan_array_count": (C.c_int32, []),
     "mp_plan_array_info": (C.c_int, [C.POINTER(PlanDims), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),

@@ -187,3 +187,60 @@ extern "C" int mp_robot_to_world(int32_t n_pts, const double *x, const double *y
                        x, y, pt_scn, rot, trans, wx, wy);
     return scene_launch_check("mp_robot_to_world");
 }
+
+// ---------------------------------------------------------------------------
+// Result record of one scenario for the gather across GPUs (nothing in the
+// reference corresponds to it).  Bytes, little endian:
+//   [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
+//   | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1) | zero padding to a multiple of 8
+// One thread per output byte, so stores are coalesced.
+__global__ void pack_results_kernel(int B, int n_s, int n_t, int width, const int32_t *path_idx,
+                                    const int32_t *status, const int32_t *layers_done, const double *best_cost,
+                                    const int32_t *st_path, const int32_t *st_len, unsigned char *out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)B * width) return;
+    const int b = (int)(g / width), o = (int)(g - (size_t)b * width);
+    unsigned v = 0;
+    if (o < 8) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(best_cost ? best_cost[b] : 0.0);
+        v = (unsigned)(bits >> (8 * o));
+    } else if (o < 10) {
+        v = (unsigned)layers_done[b] >> (8 * (o - 8));
+    } else if (o == 10) {
+        v = (unsigned)status[b];
+    } else if (o == 11) {
+        v = (unsigned)st_len[b];
+    } else if (o < 12 + 2 * n_t) {
+        const int k = (o - 12) >> 1;
+        v = (unsigned)st_path[(size_t)b * n_t + k] >> (8 * ((o - 12) & 1));
+    } else if (o < 12 + 2 * n_t + n_s) {
+        v = (unsigned)path_idx[(size_t)b * n_s + (o - 12 - 2 * n_t)];
+    }
+    out[g] = (unsigned char)(v & 0xFFu);
+}
+
+extern "C" int32_t mp_result_record_bytes(int32_t n_s, int32_t n_t)
+{
+    if (n_s <= 0 || n_t <= 0) return -1;
+    return (12 + 2 * n_t + n_s + 7) & ~7;
+}
+
+extern "C" int mp_pack_results(int32_t B, int32_t n_s, int32_t n_t, const int32_t *path_idx, const int32_t *status,
+                               const int32_t *layers_done, const double *best_cost, const int32_t *st_path,
+                               const int32_t *st_len, void *records, void *stream)
+{
+    if (B <= 0 || n_s <= 0 || n_t <= 0) { mp_set_error("bad sizes"); return MP_E_BADARG; }
+    if (!path_idx || !status || !layers_done || !st_path || !st_len || !records) {
+        mp_set_error("null array");
+        return MP_E_BADARG;
+    }
+    const int width = mp_result_record_bytes(n_s, n_t);
+    const size_t total = (size_t)B * width;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       B, n_s, n_t, width, path_idx, status, layers_done, best_cost, st_path, st_len,
+                       (unsigned char *)records);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mp_set_error("mp_pack_results: %s", hipGetErrorString(e)); return MP_E_LAUNCH; }
+    return MP_OK;
+}

@@ -4,7 +4,14 @@ A plan never spans GPUs: scenarios are independent, so rank r of W takes one
 contiguous block of scenarios and the only communication is one all-gather of
 a small fixed-size record per scenario (RCCL over xGMI on GPUs; the same code
 runs over gloo on CPU tensors, which is how it is tested without GPUs).
+
+Record layout (bytes, little endian; the library's mp_pack_results writes the
+same on the device):
+  [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
+  | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1) | zero padding to a multiple of 8
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -17,37 +24,53 @@ def shard_range(n_total, rank, world):
 
 
 def record_width(n_s, n_t):
-    """int32 words per scenario: path_idx[n_s] status layers_done best_cost(2)
-    st_path[n_t] st_len."""
-    return n_s + 2 + 2 + n_t + 1
+    """Bytes per scenario record."""
+    return (12 + 2 * n_t + n_s + 7) & ~7
 
 
 def pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=None):
-    """One int32 row per scenario (best_cost travels as its two 32-bit halves)."""
+    """One record per scenario, uint8 [B, record_width].  CUDA tensors are packed by
+    the library's kernel (one launch), CPU tensors with torch."""
     B, n_s = path_idx.shape
     n_t = st_path.shape[1]
+    width = record_width(n_s, n_t)
     if out is None:
-        out = torch.empty((B, record_width(n_s, n_t)), dtype=torch.int32, device=path_idx.device)
-    out[:, :n_s] = path_idx
-    out[:, n_s] = status
-    out[:, n_s + 1] = layers_done
-    out[:, n_s + 2:n_s + 4] = best_cost.contiguous().view(torch.int32).view(B, 2)
-    out[:, n_s + 4:n_s + 4 + n_t] = st_path
-    out[:, n_s + 4 + n_t] = st_len
+        out = torch.empty((B, width), dtype=torch.uint8, device=path_idx.device)
+    if path_idx.is_cuda:
+        from . import _lib
+        from .batch import _p, _stream
+        args = [t.contiguous() for t in (path_idx, status, layers_done, best_cost, st_path, st_len)]
+        _lib.check(_lib.lib().mp_pack_results(B, n_s, n_t, *[_p(t) for t in args], _p(out), _stream()),
+                   "mp_pack_results")
+        return out
+    out.zero_()
+    out[:, 0:8] = best_cost.contiguous().view(torch.uint8).view(B, 8)
+    out[:, 8:10] = layers_done.to(torch.int16).contiguous().view(torch.uint8).view(B, 2)
+    out[:, 10] = status.to(torch.int8).view(torch.uint8)
+    out[:, 11] = st_len.to(torch.uint8)
+    out[:, 12:12 + 2 * n_t] = st_path.to(torch.int16).contiguous().view(torch.uint8).view(B, 2 * n_t)
+    out[:, 12 + 2 * n_t:12 + 2 * n_t + n_s] = (path_idx & 0xFF).to(torch.uint8)
     return out
 
 
 def unpack_results(rec, n_s, n_t):
+    """Records -> dict of int32 / float64 tensors (path_idx, status, layers_done,
+    best_cost, st_path, st_len)."""
     rec = rec.contiguous()
-    return dict(path_idx=rec[:, :n_s], status=rec[:, n_s], layers_done=rec[:, n_s + 1],
-                best_cost=rec[:, n_s + 2:n_s + 4].contiguous().view(torch.float64).view(-1),
-                st_path=rec[:, n_s + 4:n_s + 4 + n_t], st_len=rec[:, n_s + 4 + n_t])
+    B = rec.shape[0]
+    path = rec[:, 12 + 2 * n_t:12 + 2 * n_t + n_s].to(torch.int32)
+    return dict(path_idx=torch.where(path == 255, torch.full_like(path, -1), path),
+                status=rec[:, 10].contiguous().view(torch.int8).to(torch.int32),
+                layers_done=rec[:, 8:10].contiguous().view(torch.int16).view(B).to(torch.int32) & 0xFFFF,
+                best_cost=rec[:, 0:8].contiguous().view(torch.float64).view(B),
+                st_path=rec[:, 12:12 + 2 * n_t].contiguous().view(torch.int16).view(B, n_t).to(torch.int32),
+                st_len=rec[:, 11].to(torch.int32))
 
 
 def gather_results(rec, out=None, group=None):
     """All ranks receive every rank's records in rank order.  Equal shard sizes
-    use one all_gather_into_tensor (a single direct exchange: the payload is a
-    few hundred bytes per scenario); ragged shards are padded to the largest."""
+    use one all_gather_into_tensor (a single direct exchange: the payload is about a
+    hundred bytes per scenario); ragged shards are padded to the largest."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return rec
@@ -68,7 +91,8 @@ def gather_results(rec, out=None, group=None):
     return torch.cat([buf[r * m:r * m + sizes[r]] for r in range(world)])
 
 
-def gather_results_same_size(rec, out, group=None):
-    """Hot-loop form: shard sizes known to be equal, output preallocated."""
-    dist.all_gather_into_tensor(out, rec, group=group)
-    return out
+def gather_results_same_size(rec, out, group=None, async_op=False):
+    """Hot-loop form: shard sizes known to be equal, output preallocated.  With
+    async_op the collective runs on the process group's own stream and the returned
+    handle is waited on later, so the next batch's kernels overlap the exchange."""
+    return dist.all_gather_into_tensor(out, rec, group=group, async_op=async_op)

@@ -168,3 +168,27 @@ def test_robot_to_world_inverts_ingest():
     kx, ky = r["knots_x"].cpu().numpy(), r["knots_y"].cpu().numpy()
     want = np.einsum("bij,bwj->bwi", rot, np.stack([kx, ky], 2)) + trans[:, None, :]
     close(np.stack([wx.view(B, W).cpu().numpy(), wy.view(B, W).cpu().numpy()], 2), want, atol=1e-11)
+
+
+def test_pack_results_device_matches_host():
+    """The library's record-packing kernel writes the bytes dist.pack_results writes on the
+    CPU (the form the gloo tests exercise), and unpacking returns the inputs."""
+    import torch
+    from motion_planning_amd import dist as mdist
+    rng = np.random.default_rng(8)
+    B, n_s, n_t = 300, 13, 11
+    path = torch.as_tensor(rng.integers(-1, 255, (B, n_s)).astype(np.int32))
+    status = torch.as_tensor(rng.integers(-4, 2, B).astype(np.int32))
+    layers = torch.as_tensor(rng.integers(0, 600, B).astype(np.int32))
+    best = torch.as_tensor(np.where(rng.random(B) < 0.2, np.nan, rng.uniform(0, 1e9, B)))
+    st_path = torch.as_tensor(rng.integers(-1, 1024, (B, n_t)).astype(np.int32))
+    st_len = torch.as_tensor(rng.integers(0, n_t + 1, B).astype(np.int32))
+    host = mdist.pack_results(path, status, layers, best, st_path, st_len)
+    dev = mdist.pack_results(*[t.cuda() for t in (path, status, layers, best, st_path, st_len)])
+    torch.cuda.synchronize()
+    assert host.shape == (B, mdist.record_width(n_s, n_t)) and torch.equal(host, dev.cpu())
+    u = mdist.unpack_results(dev, n_s, n_t)
+    assert torch.equal(u["path_idx"].cpu(), path) and torch.equal(u["status"].cpu(), status)
+    assert torch.equal(u["layers_done"].cpu(), layers) and torch.equal(u["st_path"].cpu(), st_path)
+    assert torch.equal(u["st_len"].cpu(), st_len)
+    assert torch.equal(u["best_cost"].cpu().view(torch.int64), best.view(torch.int64))
