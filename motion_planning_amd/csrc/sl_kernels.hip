@@ -1293,7 +1293,7 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
     a.pair_cap = cap;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
-    if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
+    if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
     const int threads = ((n_l + 63) / 64) * 64;
     hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
     return launch_check("mp_sl_plan");

@@ -239,6 +239,32 @@ def test_sl_empty_edge_and_capacity_status():
     assert r["status"] == _lib.MP_SL_FOUND                  # no obstacles: empty edge costs 0
 
 
+def test_sl_largest_fused_lattice(oracle):
+    """256 layers x 256 lanes, the largest lattice the fused kernel takes (its predecessor
+    table alone is 64 KB of LDS): fused == edge tensor + DP kernel bit for bit, and the first
+    layers against the oracle."""
+    rng = np.random.default_rng(41)
+    B, n_s, n_l = 2, 256, 256
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 0.5, 40, 0.2, 0.5, None, False)
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False)
+    res_split, _ = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False, split=True)
+    for b in range(B):
+        assert res[b]["layers_done"] == n_s and res[b]["status"] in (0, 1)
+        assert np.array_equal(res[b]["cost_map"], res_split[b]["cost_map"])
+        assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
+        assert np.array_equal(res[b]["path_idx"], res_split[b]["path_idx"])
+        n = 6
+        ref = oracle.sl_find_path(s_map[b, :n], l_map[b, :n], mid_l, ego[b], obs[b], ob_dist[b], no_early_exit=True,
+                                  want_edges=True)
+        assert_costs(res[b]["cost_map"][:n], ref["cost_map"])
+        bad = np.argwhere(res[b]["index_map"][:n] != ref["index_map"])
+        for s_, l_ in bad:   # only exact ties may differ
+            cand = ref["edge_cost"][s_, l_, :] + ref["cost_map"][s_ - 1]
+            a_, b_ = cand[res[b]["index_map"][s_, l_]], cand[ref["index_map"][s_, l_]]
+            assert abs(a_ - b_) <= 1e-9 * max(abs(a_), abs(b_))
+
+
 def test_sl_unsupported_size_is_an_error():
     from motion_planning_amd import batch as mb, _lib
     B, n_s, n_l = 1, 2, 300
