@@ -541,7 +541,8 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
         const size_t lds = (size_t)2 * d.m_max * sizeof(double);
         if (lds > 64 * 1024) { mp_set_error("m_max too large"); return MP_E_UNSUPPORTED; }
         const int n_slot = d.n_st_max + d.n_dy_max * d.n_frames;
-        const int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);
+        int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);
+        if (const char *t_env = getenv("MP_FE_THREADS")) threads = atoi(t_env); // development aid
         hipLaunchKernelGGL(plan_frontend_kernel, dim3(B), dim3(threads), lds, st, f);
         rc = pipe_launch_check("mp_plan_scenes (front end)");
         if (rc) return rc;

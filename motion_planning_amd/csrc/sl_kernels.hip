@@ -527,7 +527,7 @@ __global__ void sl_plan_kernel(SlDev a)
     const int64_t rstride = a.in.l_rstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
-    const int n_ob = a.in.n_ob[b];
+    const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride); // never past the scenario's obstacle slots
     const double r = a.in.ob_dist[b], r2 = r * r;
     const double d_s = a.p.d_s, w_d = a.p.w_d;
     const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;
@@ -791,7 +791,7 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     const int64_t rstride = a.in.l_rstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
-    const int n_ob = a.in.n_ob[b];
+    const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride); // never past the scenario's obstacle slots
     const double r = a.in.ob_dist[b], r2 = r * r;
     const double d_s = a.p.d_s, w_d = a.p.w_d;
     const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;
@@ -1023,7 +1023,7 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
-    const int n_ob = a.in.n_ob[b];
+    const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride); // never past the scenario's obstacle slots
     const double r = a.in.ob_dist[b], r2 = r * r;
     const double d_s = a.p.d_s, w_d = a.p.w_d;
     const double cG = w_d * d_s, cS = (1.0 - w_d) * d_s;

@@ -75,7 +75,7 @@ struct StCell {
         for (int k = 0; k < RT; ++k) {
             const double d = __dsub_rn(fs, dn[k]);
             const double t = (s >= __dsub_rn(dn[k], front)) ? __dmul_rn(1e3, __dmul_rn(d, d)) : cst[k];
-            acc = __dadd_rn(acc, t);
+            acc = (k == 0) ? t : __dadd_rn(acc, t); // 0.0 + t == t: every term is >= +0.0
         }
         return acc;
     }
@@ -478,7 +478,9 @@ __global__ void st_regions_kernel(RegDev a)
     __shared__ int base_sh;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
-    const int P = a.n_path[b], n_st = a.n_st ? a.n_st[b] : 0, n_dy = a.n_dy ? a.n_dy[b] : 0;
+    // counts clamped to the slots the arrays have
+    const int P = min(max(a.n_path[b], 0), a.p_max);
+    const int n_st = a.n_st ? min(max(a.n_st[b], 0), a.n_st_max) : 0, n_dy = a.n_dy ? min(max(a.n_dy[b], 0), a.n_dy_max) : 0;
     double *ps = smem, *pl = smem + a.p_max;
     for (int k = tid; k < P; k += nt) {
         ps[k] = a.path_s[(size_t)b * a.p_max + k];
@@ -581,7 +583,9 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
     __shared__ double box_sh[4][16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
-    const int P = a.n_path[b], n_st = a.n_st ? a.n_st[b] : 0, n_dy = a.n_dy ? a.n_dy[b] : 0;
+    // counts clamped to the slots the arrays have
+    const int P = min(max(a.n_path[b], 0), a.p_max);
+    const int n_st = a.n_st ? min(max(a.n_st[b], 0), a.n_st_max) : 0, n_dy = a.n_dy ? min(max(a.n_dy[b], 0), a.n_dy_max) : 0;
     const int n_t = a.n_t;
     double *ps = smem, *pl = smem + a.p_max;
     double *res_dn = pl + a.p_max, *res_u = res_dn + n_items_max;
