@@ -343,11 +343,30 @@ __global__ void st_dp_kernel(StDev a)
     const int d_lim = *d_lim_sh;
     double m_prev = 0.0; // minimum of cost_prev
 
+    // the blocked intervals of a layer are fetched from global memory while the layer
+    // before it is relaxed (one interval per thread; any beyond blockDim are read directly)
+    int R_next = min(max(a.n_reg[(size_t)b * n_t + 1], 0), R_max);
+    double pf_down = 0.0, pf_up = 0.0;
+    if (tid < R_next) {
+        pf_down = a.s_down[((size_t)b * n_t + 1) * R_max + tid];
+        pf_up = a.s_up[((size_t)b * n_t + 1) * R_max + tid];
+    }
     for (int i = 1; i < n_t; ++i) {
-        const int R = a.n_reg[(size_t)b * n_t + i];
-        for (int k = tid; k < R; k += nt) {
+        const int R = R_next;
+        if (tid < R) {
+            sh.down[tid] = pf_down;
+            sh.up[tid] = pf_up;
+        }
+        for (int k = tid + nt; k < R; k += nt) {
             sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
             sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
+        }
+        if (i + 1 < n_t) {
+            R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
+            if (tid < R_next) {
+                pf_down = a.s_down[((size_t)b * n_t + i + 1) * R_max + tid];
+                pf_up = a.s_up[((size_t)b * n_t + i + 1) * R_max + tid];
+            }
         }
         __syncthreads();
         double m_loc = MP_INF;
@@ -406,12 +425,16 @@ __global__ void st_dp_kernel(StDev a)
         m_loc = wave_min_f64(m_loc);
         if ((tid & (MP_WAVE - 1)) == 0) red[wave] = m_loc;
         __syncthreads();
-        for (int j = tid; j < n_s; j += nt) sh.cost_prev[j] = sh.cost_cur[j];
         if (tid == 0) last_col[i] = sh.cost_cur[n_s - 1];
         m_prev = red[0];
         for (int w = 1; w < nw; ++w) m_prev = red[w] < m_prev ? red[w] : m_prev;
-        __syncthreads();
+        // the two cost rows swap roles; the next layer overwrites `red` and the other row
+        // only after its own first barrier
+        double *row = sh.cost_prev;
+        sh.cost_prev = sh.cost_cur;
+        sh.cost_cur = row;
     }
+    __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
         const double *cost_prev = sh.cost_prev;
