@@ -215,8 +215,12 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // cells are taken from the far end downwards: whatever is left over for the last,
     // partly filled pass are then the cells next to s = 0, which have the fewest
     // predecessors, instead of the ones with the most
-    for (int jb = 0; jb < n_s; jb += G) {
-        const int j = n_s - 1 - (jb + g);
+    // ... and passes alternate the direction in which the lane groups take their cells: a
+    // wave's position in the workgroup also fixes the SIMD it runs on, so a fixed direction
+    // would hand the longest cells of every pass to the same SIMD
+    bool flip = false;
+    for (int jb = 0; jb < n_s; jb += G, flip = !flip) {
+        const int j = n_s - 1 - (jb + (flip ? G - 1 - g : g));
         const bool live = j >= 0;
         double best = MP_INF;
         int bp = 0x7fffffff;
