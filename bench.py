@@ -128,6 +128,13 @@ def cpu_pipeline(sc, n_sample, threads):
     return n_sample / dt, dt
 
 
+def exchange_on(world):
+    """The result exchange runs with more than one rank; MP_BENCH_FORCE_DIST=1 also runs it
+    (process group, barrier, all-gather, max over ranks) in a one-rank job, which is how the
+    RCCL calls are rehearsed on a one-GPU box."""
+    return world > 1 or os.environ.get("MP_BENCH_FORCE_DIST") == "1"
+
+
 class ResultGather:
     """The per-step exchange of result records when more than one GPU takes part: pack on
     the device (one kernel), then one all-gather issued asynchronously on the process
@@ -140,7 +147,8 @@ class ResultGather:
         from motion_planning_amd import dist as mdist
         self.world, self.backend, self.mdist = world, backend, mdist
         self.k = 0
-        if world == 1:
+        self.active = exchange_on(world)
+        if not self.active:
             return
         width = mdist.record_width(n_s, n_t)
         gdev = "cuda" if backend == "nccl" else "cpu"
@@ -149,7 +157,7 @@ class ResultGather:
         self.pending = [None, None]
 
     def submit(self, path_idx, status, layers_done, best_cost, st_path, st_len):
-        if self.world == 1:
+        if not self.active:
             return
         i = self.k & 1
         if self.pending[i] is not None:
@@ -160,7 +168,7 @@ class ResultGather:
         self.k += 1
 
     def drain(self):
-        if self.world == 1:
+        if not self.active:
             return
         for i in range(2):
             if self.pending[i] is not None:
@@ -196,7 +204,7 @@ def bench_pipeline(args, world, rank, backend):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -210,7 +218,7 @@ def bench_pipeline(args, world, rank, backend):
     gather.drain()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -327,7 +335,9 @@ def main():
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    if exchange_on(world):
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)   # a forced one-rank job started without a launcher
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -335,7 +345,7 @@ def main():
 
     if args.workload == "pipeline":
         bench_pipeline(args, world, rank, backend)
-        if world > 1:
+        if exchange_on(world):
             dist.destroy_process_group()
         return
     B = args.scenarios
@@ -365,7 +375,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -379,7 +389,7 @@ def main():
     gather.drain()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange_on(world):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -393,7 +403,7 @@ def main():
     assert bad == 0, "kernel reported %d scenarios with an error status" % bad
     assert int(st["path_len"].min()) >= 2
 
-    if world > 1:
+    if exchange_on(world):
         # every rank holds every scenario's record, in scenario order
         gathered = gather.last()
         u = mdist.unpack_results(gathered[rank * B:(rank + 1) * B].to("cuda"), N_S, ST_N_T)
@@ -466,7 +476,7 @@ def main():
                                    "sample": "first %d scenarios of the same batch (SL every layer + ST), "
                                              "C oracle, %d threads, %.1f s" % (min(args.cpu_sample, B), threads, dt)}
         print(json.dumps(res))
-    if world > 1:
+    if exchange_on(world):
         dist.destroy_process_group()
 
 
