@@ -107,14 +107,17 @@ def random_scene(rng, n_st, n_dy):
                 st_rad=np.full(n_st, 0.8), dy_pos=np.stack(frames, 1), dy_rad=np.full(n_dy, 0.8))
 
 
-def test_pipeline_random_vs_oracle(oracle):
-    """Curved 13-21 knot lines, a mix of sparse and crowded scenes."""
+@pytest.mark.parametrize("n_l", [5, 12, 128])
+def test_pipeline_random_vs_oracle(oracle, n_l):
+    """Curved 13-21 knot lines, a mix of sparse and crowded scenes; the default 5 lanes
+    (lane-per-edge SL kernel) and wider lattices (12: the same kernel at 16 lanes per target, 128: the
+    workgroup-per-scene SL kernel inside the chain)."""
     import torch
     from motion_planning_amd import pipeline as pl
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + n_l)
     scenes = [random_scene(rng, *cnt) for cnt in [(6, 2), (12, 3), (24, 6), (3, 0), (0, 0), (0, 2), (40, 8), (10, 4),
                                                   (192, 64), (5, 1)]]
-    r = pl.plan_batch(**pack_scenes(scenes))
+    r = pl.plan_batch(**pack_scenes(scenes), n_l=n_l)
     torch.cuda.synchronize()
     status = r["status"].cpu().numpy()
     n_found = 0
@@ -122,7 +125,7 @@ def test_pipeline_random_vs_oracle(oracle):
         st = [(pos, rad) for pos, rad in zip(sc["st_pos"], sc["st_rad"])]
         dy = [(fr, rad) for fr, rad in zip(sc["dy_pos"], sc["dy_rad"])]
         try:
-            sl = oracle.SLMap(sc["rx"], sc["ry"], 0.0, sc["ego_vel"], st, dy)
+            sl = oracle.SLMap(sc["rx"], sc["ry"], 0.0, sc["ego_vel"], st, dy, n_l=n_l)
         except ValueError:   # Frenet map longer than 100 m
             assert status[b] == pl.PIPE_MAP_TOO_BIG
             continue
