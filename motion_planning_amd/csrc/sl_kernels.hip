@@ -1286,15 +1286,23 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     // pair store: 3.5 pairs per obstacle slot (an obstacle of radius r meets about
     // 2r/d_s + 1 samples, a few of them twice where two layers share a sample),
     // fewer if LDS would not hold it; layers past its end test their pairs directly
+    const int threads = ((n_l + 63) / 64) * 64;
     int cap = (7 * batch->ob_stride) / 2;
     if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) cap = atoi(cap_env); // tests: force the overflow path
+    else {
+        // registers allow 16 waves per CU; a store that lets LDS hold fewer workgroups than
+        // that costs more (idle SIMDs) than laying a smaller store out again every few layers
+        const size_t budget = (size_t)10 * 1024 * (threads / 64), fixed = sl_plan_lds_bytes(n_s, n_l, 0);
+        const int fit = budget > fixed ? (int)((budget - fixed) / (3 * sizeof(double))) : 0;
+        const int floor_cap = 128;
+        if (cap > fit) cap = fit > floor_cap ? fit : (cap < floor_cap ? cap : floor_cap);
+    }
     cap = cap < 2 ? 2 : (cap > 16384 ? 16384 : cap);
-    cap += cap & 1;
+    cap &= ~1;
     while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
     a.pair_cap = cap;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
     if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
-    const int threads = ((n_l + 63) / 64) * 64;
     hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
     return launch_check("mp_sl_plan");
 }
