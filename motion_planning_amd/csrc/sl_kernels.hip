@@ -205,7 +205,12 @@ struct Collider {
 #pragma unroll
             for (int e = 0; e < NE; ++e) h |= pair_hit(l1, dl, h0[e], ol[e], ds2[e], r2);
         } else if constexpr (NE == -1) {
-            for (int e = 0; e < n_ent; ++e) h |= pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
+            // in blocks of 8, so that a wave whose edges have all hit something stops early
+            // (crowded layers have hundreds of pairs)
+            for (int e0 = 0; e0 < n_ent && !h; e0 += 8) {
+                const int e1 = e0 + 8 < n_ent ? e0 + 8 : n_ent;
+                for (int e = e0; e < e1; ++e) h |= pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
+            }
         } else if constexpr (NE == -2) {
             const double T = p2s - p1s;
             for (int k = 0; k < g.K; ++k) {
@@ -427,31 +432,47 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     int bj = j0;
     // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
     // m_prev + cSH*dl^2 up to rounding, which the slack terms cover
-    double w2 = MP_INF;
-    if (w_inv > 0.0) {
-        double gap = best - m_prev;
-        gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
-        w2 = gap * w_inv;
-    }
-    for (int j = j0 - 1; j >= 0; --j) {
-        lc = src.lc[j];
-        const double dl = l2v - lc.x;
-        if (dl * dl > w2) {
-            if (sorted && dl > 0.0) break; // sources further down are further away
-            continue;
+    // (the window follows `best` down: a free edge found next to a blocked one ends the walk)
+    auto window = [&](double bst) {
+        double gap = bst - m_prev;
+        gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(bst));
+        return gap * w_inv;
+    };
+    double w2 = w_inv > 0.0 ? window(best) : MP_INF;
+    // outwards on both sides in turn, so that a free edge close by is found (and shrinks
+    // the window) before the far side of a blocked stretch has been walked
+    int jd = j0 - 1, ju = j0 + 1;
+    while (jd >= 0 || ju < n_src) {
+        if (jd >= 0) {
+            lc = src.lc[jd];
+            const double dl = l2v - lc.x;
+            if (dl * dl > w2) {
+                jd = (sorted && dl > 0.0) ? -1 : jd - 1; // sorted: sources further down are further away
+            } else {
+                const double c = eval(jd, lc.x, lc.y, dl);
+                if (c < best || (c == best && jd < bj)) { // lower index wins ties
+                    best = c;
+                    bj = jd;
+                    if (w_inv > 0.0) w2 = window(best);
+                }
+                --jd;
+            }
         }
-        const double c = eval(j, lc.x, lc.y, dl);
-        if (c <= best) { best = c; bj = j; } // lower index wins ties
-    }
-    for (int j = j0 + 1; j < n_src; ++j) {
-        lc = src.lc[j];
-        const double dl = l2v - lc.x;
-        if (dl * dl > w2) {
-            if (sorted && dl < 0.0) break;
-            continue;
+        if (ju < n_src) {
+            lc = src.lc[ju];
+            const double dl = l2v - lc.x;
+            if (dl * dl > w2) {
+                ju = (sorted && dl < 0.0) ? n_src : ju + 1;
+            } else {
+                const double c = eval(ju, lc.x, lc.y, dl);
+                if (c < best || (c == best && ju < bj)) {
+                    best = c;
+                    bj = ju;
+                    if (w_inv > 0.0) w2 = window(best);
+                }
+                ++ju;
+            }
         }
-        const double c = eval(j, lc.x, lc.y, dl);
-        if (c < best) { best = c; bj = j; }
     }
     *bj_out = bj;
     return best;
