@@ -414,7 +414,7 @@ struct SrcSh {
 // predecessor first, then outward walks that stop once cS*H*dl^2 alone exceeds
 // the best cost so far.  w_inv = 1/(cS*H) with its safety factor, or 0 when
 // the bound does not apply.  Returns the accumulated cost; *bj_out = predecessor.
-template <int NE>
+template <int NE, bool BOUND_FIRST = false>
 __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, double l2v, double Q, double w_inv,
                                                double m_prev, double g_max, bool sorted, double pen,
                                                const Collider<NE> &col, int *bj_out)
@@ -439,6 +439,25 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
         return gap * w_inv;
     };
     double w2 = w_inv > 0.0 ? window(best) : MP_INF;
+    // BOUND_FIRST (layers with many pairs): a candidate is first priced without the obstacle
+    // penalty (a lower bound of its cost, since the penalty only adds and rounding is
+    // monotone) and its pairs are only looked at if that bound could still win.
+    auto consider = [&](int j, double l1, double cp, double dl) {
+        const double u = l1 - src.mid;
+        const double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
+        double c;
+        if constexpr (BOUND_FIRST) {
+            c = e + cp;
+            if (!(c < best || (c == best && j < bj))) return; // lower index wins ties
+            if (col.hit(l1, dl)) c = (e + pen) + cp;
+        } else {
+            c = (e + (col.hit(l1, dl) ? pen : 0.0)) + cp;
+        }
+        if (!(c < best || (c == best && j < bj))) return;
+        best = c;
+        bj = j;
+        if (w_inv > 0.0) w2 = window(best);
+    };
     // outwards on both sides in turn, so that a free edge close by is found (and shrinks
     // the window) before the far side of a blocked stretch has been walked
     int jd = j0 - 1, ju = j0 + 1;
@@ -449,12 +468,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 jd = (sorted && dl > 0.0) ? -1 : jd - 1; // sorted: sources further down are further away
             } else {
-                const double c = eval(jd, lc.x, lc.y, dl);
-                if (c < best || (c == best && jd < bj)) { // lower index wins ties
-                    best = c;
-                    bj = jd;
-                    if (w_inv > 0.0) w2 = window(best);
-                }
+                consider(jd, lc.x, lc.y, dl);
                 --jd;
             }
         }
@@ -464,12 +478,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 ju = (sorted && dl < 0.0) ? n_src : ju + 1;
             } else {
-                const double c = eval(ju, lc.x, lc.y, dl);
-                if (c < best || (c == best && ju < bj)) {
-                    best = c;
-                    bj = ju;
-                    if (w_inv > 0.0) w2 = window(best);
-                }
+                consider(ju, lc.x, lc.y, dl);
                 ++ju;
             }
         }
@@ -700,7 +709,15 @@ __global__ void sl_plan_kernel(SlDev a)
             case 5:
             case 6: SL_RELAX(6) break;
             case -1: SL_RELAX(-2) break; // the pair store overflowed before this layer
-            default: SL_RELAX(-1) break; // more than 6 pairs: the list is read from LDS
+            default: // more than 6 pairs: the list is read from LDS
+                if (n_ent > 24) {
+                    Collider<-1> col;
+                    col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+                    best = relax_target<-1, true>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj);
+                } else {
+                    SL_RELAX(-1)
+                }
+                break;
             }
 #undef SL_RELAX
             idx8[(size_t)s * n_l + tid] = (unsigned char)bj;

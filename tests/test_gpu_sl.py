@@ -225,6 +225,39 @@ def test_sl_pair_store_refill(oracle, cap, n_l, monkeypatch):
             assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
 
 
+@pytest.mark.parametrize("n_l,n_pairs", [(33, 150), (65, 40), (9, 60)])
+def test_sl_mirror_symmetric_ties(oracle, n_l, n_pairs):
+    """A lattice, an ego and obstacles that are mirror images about l = 0 make the costs
+    of lanes t and n_l-1-t equal to the last bit on every layer, blocked or free: every
+    minimum is a tie and the lower index must win, whatever order the kernel visits the
+    predecessors in (crowded layers take the bound-first walk)."""
+    rng = np.random.default_rng(900 + n_l)
+    B, n_s = 6, 6
+    s_map, l_map, ego, _, ob_dist = random_batch(rng, B, n_s, n_l, 8.0, 1, 0.4, 0.9, None, False)
+    ego[:, 1] = 0.0
+    l_map = (l_map - l_map[:, :, ::-1]) / 2.0   # exactly antisymmetric lateral rows
+    obs = []
+    for b in range(B):
+        n = max(4, n_pairs >> (2 * (b % 3)))   # crowded, moderate and sparse scenes
+        half = np.stack([rng.uniform(0.5, s_map[b, 2 + b % 3, 0], n), rng.uniform(0.05, 2.5, n)], 1)
+        obs.append(np.concatenate([half, half * np.array([1.0, -1.0])]))
+    mid_l = int((n_l - 1) / 2)
+    n_ties = 0
+    for early in (True, False):
+        res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early)
+        res_split, _ = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early, split=True)
+        for b in range(B):
+            ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b],
+                                      no_early_exit=not early, want_edges=True)
+            assert_sl_parity(res[b], ref, ref.get("edge_cost"))
+            assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
+            d = ref["layers_done"]
+            cm = ref["cost_map"][:d]
+            assert np.array_equal(cm, cm[:, ::-1])      # the symmetry is exact
+            n_ties += d
+    assert n_ties > 0
+
+
 def test_sl_empty_edge_and_capacity_status():
     from motion_planning_amd import _lib
     s_map = np.array([[[8.0] * 5, [8.2] * 5]])            # second gap shorter than d_s

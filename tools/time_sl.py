@@ -1,22 +1,43 @@
-"""Ad-hoc timing of the fused SL kernel over batch sizes (development aid): the
-time-vs-batch staircase shows how many workgroups a CU holds at once."""
-import sys, numpy as np, torch
-sys.path.insert(0, '.')
-from motion_planning_amd import batch as mb
-import bench
+"""Ad-hoc timing of the fused SL plan kernel on the bench's lattice workload
+(development aid).  MP_LIB_PATH=<other build> times that library instead.
 
-sc = bench.make_scenarios(0, 4096)
-prm = mb.sl_params(early_exit=False, n_l=bench.N_L)
-for B in [int(x) for x in (sys.argv[1:] or "256 1024 1536 1792 2048 2304 3584 4096".split())]:
-    sb = mb.SLBatch(sc["s_layers"][:B], sc["l_row"][:B], sc["ego"][:B], sc["ob_s"][:B], sc["ob_l"][:B],
-                    sc["n_ob"][:B], sc["ob_dist"][:B])
-    out = mb.SLPlanOut(B, bench.N_S, bench.N_L, want_maps=False)
-    for _ in range(3):
+    python3 tools/time_sl.py [B] [repeats]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from motion_planning_amd import _lib
+if os.environ.get('MP_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['MP_LIB_PATH']   # A/B timing against another build
+from motion_planning_amd import batch as mb
+from bench import N_L, N_S, make_scenarios
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    sc = make_scenarios(0, B)
+    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
+    prm = mb.sl_params(early_exit=False, n_l=N_L)
+    out = mb.SLPlanOut(B, N_S, N_L, want_maps=False)
+    for _ in range(5):
         mb.sl_plan(sb, prm, out)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
+    best = 1e9
+    tot = 0.0
+    for _ in range(reps):
+        e0.record()
         mb.sl_plan(sb, prm, out)
-    e1.record(); torch.cuda.synchronize()
-    print("B=%d: %.3f ms" % (B, e0.elapsed_time(e1) / 10))
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1)
+        best = min(best, t)
+        tot += t
+    print("sl_plan B=%d: mean %.4f ms, best %.4f ms (%s)" % (B, tot / reps, best, _lib.LIB_PATH))
+
+
+if __name__ == "__main__":
+    main()
