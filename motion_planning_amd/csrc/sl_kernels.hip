@@ -908,7 +908,25 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
         bool ent_stored;
         const int n_ent = ps.layer_pairs(s, &ent_off, &ent_stored);
         bool hit = false;
-        if (ent_stored) {
+        if (ent_stored && n_l * n_l <= 32) {
+            // Up to 5 lanes: the edges of a layer fill at most half of the (single) wave, so
+            // the wave holds every edge 64/Es times (Es = 4, 16 or 32 lanes per copy) and each
+            // copy takes every (64/Es)-th pair; a ballot brings the copies' verdicts together.
+            const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
+            const int n_e = n_l * n_l, Es = n_e <= 4 ? 4 : (n_e <= 16 ? 16 : 32), P = MP_WAVE / Es;
+            const int ee = lane & (Es - 1), part = lane / Es;
+            const int t2 = ee / n_l, j2 = ee - t2 * n_l;
+            const bool e_valid = ee < n_e && j2 < n_src;
+            // the edge's end points, from the lanes that hold them in the (t, j) layout
+            const double l2b = __shfl(l2v, e_valid ? t2 * W : 0, MP_WAVE);
+            const double l1b = __shfl(lcj.x, e_valid ? j2 : 0, MP_WAVE);
+            const double dlb = l2b - l1b;
+            bool h = false;
+            for (int e = part; e < n_ent; e += P) h |= pair_hit(l1b, dlb, e_h0[e], e_ol[e], e_ds2[e], r2);
+            unsigned long long m = __ballot(h && e_valid);
+            for (int p = 1; p < P; ++p) m |= m >> (p * Es); // bit e of the low copy: any copy hit
+            hit = valid && ((m >> (t * n_l + j)) & 1ull);
+        } else if (ent_stored) {
             const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
             for (int e = 0; e < n_ent; ++e) hit |= pair_hit(lcj.x, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
         } else if (3 * cap >= 2 * K) {

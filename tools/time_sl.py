@@ -20,6 +20,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     sc = make_scenarios(0, B)
+    if os.environ.get('SL_NO_OB'):   # the same lattice without obstacles: the DP's fixed cost per layer
+        sc["n_ob"] = sc["n_ob"] * 0
     sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
     prm = mb.sl_params(early_exit=False, n_l=N_L)
     out = mb.SLPlanOut(B, N_S, N_L, want_maps=False)
