@@ -420,7 +420,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
                                                const Collider<NE> &col, int *bj_out)
 {
     const int l2 = threadIdx.x;
-    auto eval = [&](int j, double l1, double cp, double dl) {
+    auto eval = [&](double l1, double cp, double dl) {
         const double u = l1 - src.mid;
         double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
         e += col.hit(l1, dl) ? pen : 0.0;
@@ -428,7 +428,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     };
     const int j0 = min(l2, n_src - 1);
     double2 lc = src.lc[j0];
-    double best = eval(j0, lc.x, lc.y, l2v - lc.x);
+    double best = eval(lc.x, lc.y, l2v - lc.x);
     int bj = j0;
     // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
     // m_prev + cSH*dl^2 up to rounding, which the slack terms cover
@@ -606,15 +606,6 @@ __global__ void sl_plan_kernel(SlDev a)
         u_loc = -wave_min_f64(-u_loc);
         if ((tid & (MP_WAVE - 1)) == 0) red[wave] = u_loc;
     }
-    auto layer_geo = [&](int s) {
-        LayerGeom g;
-        const int kn = layK[s];
-        g.K = kn < 0 ? kn : (kn & 0xffff);
-        g.n = kn < 0 ? 0 : g.K - (kn >> 16);
-        const double p1s = (s == 0) ? ego_s : layP2[s - 1];
-        g.delta = (p1s + d_s) - p1s;
-        return g;
-    };
     // ---- prologue: the (sample, obstacle) pairs of every layer --------------------
     PairStore ps;
     ps.n_s = n_s; ps.n_ob = n_ob; ps.cap = cap;
