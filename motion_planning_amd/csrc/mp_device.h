@@ -22,18 +22,38 @@ __device__ __forceinline__ double dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// DPP moves whose control gives every lane a source lane (quad permutations and
+// mirrors): nothing of the destination survives, so no copy of it is needed.
+template <int CTRL>
+__device__ __forceinline__ int dpp_all_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_all_f64(double v)
+{
+    return __hiloint2double(dpp_all_i32<CTRL>(__double2hiint(v)), dpp_all_i32<CTRL>(__double2loint(v)));
+}
+
+#define MP_DPP_QUAD_1032 0xB1   // quad_perm [1,0,3,2]: lane ^ 1
+#define MP_DPP_QUAD_2301 0x4E   // quad_perm [2,3,0,1]: lane ^ 2
+#define MP_DPP_HALF_MIRROR 0x141 // lane k <-> 7-k inside each group of 8
+#define MP_DPP_MIRROR 0x140      // lane k <-> 15-k inside each row of 16
+
 // Minimum over the wave, returned in every lane.  Data-parallel-primitive
 // moves inside the 16-lane rows (quad swaps, half mirror, mirror), row
 // broadcasts across rows, then lane 63 is read back; no LDS traffic.
+// Costs are never NaN, so v_min_f64 stands in for compare-and-select.  Every lane of
+// the wave must be active (a DPP move from an inactive lane reads 0).
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-    double o;
-    o = dpp_f64<0xB1, 0xF>(v); v = o < v ? o : v;  // quad_perm [1,0,3,2]
-    o = dpp_f64<0x4E, 0xF>(v); v = o < v ? o : v;  // quad_perm [2,3,0,1]
-    o = dpp_f64<0x141, 0xF>(v); v = o < v ? o : v; // row_half_mirror
-    o = dpp_f64<0x140, 0xF>(v); v = o < v ? o : v; // row_mirror
-    o = dpp_f64<0x142, 0xA>(v); v = o < v ? o : v; // row_bcast15 into rows 1 and 3
-    o = dpp_f64<0x143, 0xC>(v); v = o < v ? o : v; // row_bcast31 into rows 2 and 3
+    v = __builtin_fmin(dpp_all_f64<MP_DPP_QUAD_1032>(v), v);
+    v = __builtin_fmin(dpp_all_f64<MP_DPP_QUAD_2301>(v), v);
+    v = __builtin_fmin(dpp_all_f64<MP_DPP_HALF_MIRROR>(v), v);
+    v = __builtin_fmin(dpp_all_f64<MP_DPP_MIRROR>(v), v);
+    v = __builtin_fmin(dpp_f64<0x142, 0xA>(v), v); // row_bcast15 into rows 1 and 3
+    v = __builtin_fmin(dpp_f64<0x143, 0xC>(v), v); // row_bcast31 into rows 2 and 3
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
@@ -47,11 +67,20 @@ __device__ __forceinline__ void argmin_merge(double &c, int &i, double oc, int o
     i = take ? oi : i;
 }
 
+// (cost, index) first-minimum over aligned groups of WIDTH lanes, result in every lane
+// of the group.  Inside a 16-lane row the partners come from DPP moves (after the two
+// quad steps all lanes of a quad agree, so a mirror pairs quads as well as lane ^ 4 or
+// lane ^ 8 would); wider groups finish with shuffles.  Every lane of the wave must be active.
 template <int WIDTH>
 __device__ __forceinline__ void group_argmin(double &c, int &i)
 {
+    static_assert(WIDTH >= 2 && WIDTH <= MP_WAVE && (WIDTH & (WIDTH - 1)) == 0, "group width");
+    argmin_merge(c, i, dpp_all_f64<MP_DPP_QUAD_1032>(c), dpp_all_i32<MP_DPP_QUAD_1032>(i));
+    if (WIDTH >= 4) argmin_merge(c, i, dpp_all_f64<MP_DPP_QUAD_2301>(c), dpp_all_i32<MP_DPP_QUAD_2301>(i));
+    if (WIDTH >= 8) argmin_merge(c, i, dpp_all_f64<MP_DPP_HALF_MIRROR>(c), dpp_all_i32<MP_DPP_HALF_MIRROR>(i));
+    if (WIDTH >= 16) argmin_merge(c, i, dpp_all_f64<MP_DPP_MIRROR>(c), dpp_all_i32<MP_DPP_MIRROR>(i));
 #pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) {
+    for (int m = 16; m < WIDTH; m <<= 1) {
         double oc = __shfl_xor(c, m, MP_WAVE);
         int oi = __shfl_xor(i, m, MP_WAVE);
         argmin_merge(c, i, oc, oi);
