@@ -173,6 +173,7 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
 // Per-cell interval tables in LDS, [interval][cell].
 struct StTab {
     double *dn, *cst; // [r_tab][N]
+    int *quiet;       // [N]: below this predecessor distance none of the cell's intervals takes the front formula
 };
 
 // Bytes of dynamic LDS in front of the cell tables (see st_dp_kernel).
@@ -205,9 +206,28 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
     const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
     const int n1 = n_s - 1;
+    // (tb.quiet[] was set to "never" before the barrier in front of this call)
+    const double front_step = sh.front[n_s > 1 ? 1 : 0];
     for (int q = tid; q < n_s * R; q += nt) {
         const int k = q / n_s, j = q - k * n_s;
-        StCell<1>::classify(__dmul_rn((double)j, ds), sh.down[k], sh.up[k], &tb.dn[k * N + j], &tb.cst[k * N + j]);
+        const double s = __dmul_rn((double)j, ds);
+        double dnk, ck;
+        StCell<1>::classify(s, sh.down[k], sh.up[k], &dnk, &ck);
+        tb.dn[k * N + j] = dnk;
+        tb.cst[k * N + j] = ck;
+        if (dnk != MP_INF) {
+            // A distance below which this interval cannot take the front formula: the test
+            // s >= dn - front[d] can only turn from false to true as d grows (front[] does not
+            // decrease), so it is enough that it fails at the distance just below.  The
+            // estimate only has to be close; the loop makes it safe.
+            int dq = n_s;
+            if (front_step > 0.0) {
+                const double g = (dnk - s) / front_step;
+                dq = g < (double)n_s ? (g > 0.0 ? (int)g : 0) : n_s;
+            }
+            while (dq > 0 && s >= __dsub_rn(dnk, sh.front[dq - 1])) --dq;
+            atomicMin(&tb.quiet[j], dq);
+        }
     }
     __syncthreads();
     const int r = tid & (ST_SPLIT - 1), g = tid / ST_SPLIT, G = nt / ST_SPLIT;
@@ -236,9 +256,21 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 } else { cell.dn[k] = MP_INF; cell.cst[k] = 0.0; }
             }
             const double s = __dmul_rn((double)j, ds);
+            // what the obstacle sum comes to while no interval takes the front formula: the
+            // same additions in the same order with every term at its constant
+            double ob_quiet = 0.0;
+#pragma unroll
+            for (int k = 0; k < RT; ++k) ob_quiet = (k == 0) ? cell.cst[0] : __dadd_rn(ob_quiet, cell.cst[k]);
+            const int d_quiet = RT > 0 ? tb.quiet[j] : 0;
             for (int p = j - r; p >= 0; p -= ST_SPLIT) {
                 const int d = j - p;
-                const double base = __dadd_rn(cell.ob(s, sh.front[d]), sh.speed[d]);
+                // the lanes of a wave hold neighbouring cells at nearly the same distance, so
+                // "no lane needs the front formula" is common (slow edges, obstacles far ahead)
+                // and decided for the whole wave
+                double obv;
+                if (RT > 0 && __ballot(d >= d_quiet) == 0ull) obv = ob_quiet;
+                else obv = cell.ob(s, sh.front[d]);
+                const double base = __dadd_rn(obv, sh.speed[d]);
                 if (cell.monotone && d >= d_lim && bp != 0x7fffffff && __dadd_rn(base, m_prev) > best) break;
                 const int pp = pre1[p];
                 const int n = d - (p - pp);
@@ -298,6 +330,7 @@ __global__ void st_dp_kernel(StDev a)
     const size_t tab_off = st_tab_offset(N, R_max, n_t);
     tb.dn = smem + tab_off / 8;
     tb.cst = tb.dn + (size_t)a.r_tab * N;
+    tb.quiet = (int *)(tb.cst + (size_t)a.r_tab * N);
 
     const double ds = a.ds, dt = a.dt, lim = a.speed_lim;
     const double v0 = a.cur_vel[b];
@@ -365,6 +398,7 @@ __global__ void st_dp_kernel(StDev a)
             sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
             sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
         }
+        for (int j = tid; j < n_s; j += nt) tb.quiet[j] = 0x7fffffff;
         if (i + 1 < n_t) {
             R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
             if (tid < R_next) {
@@ -749,7 +783,8 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // wide grid gets more lanes per layer
     if (B <= 512 && n_s_max > 64) threads = 512;
     if (th_env) threads = atoi(th_env);
-    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double);
+    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double) +
+                 (size_t)n_s_max * sizeof(int);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     hipLaunchKernelGGL(st_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return st_launch_check("mp_st_dp");
