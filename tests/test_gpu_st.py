@@ -145,6 +145,37 @@ def test_st_exact_ties_pick_the_first_predecessor(oracle):
     assert tied > 0     # the data really contains exact ties
 
 
+@pytest.mark.parametrize("n_s_max", [40, 97])
+def test_st_front_term_switches_on_exactly_at_grid_values(oracle, n_s_max):
+    """Interval starts on whole and half metres: with ds = 1 and dt = 0.5 the look-ahead
+    4.5 v is a whole number of metres too, so `s >= s_down - 4.5 v` is met with equality
+    on many edges -- the distance from which a cell's intervals can take the front formula
+    has to be exact there.  Scenes mix intervals far ahead (never reached), just ahead,
+    behind, and none at all."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(40 + n_s_max)
+    B, n_t, r_max = 24, 11, 5
+    n_s = rng.integers(n_s_max // 2, n_s_max + 1, B).astype(np.int32)
+    n_s[0] = n_s_max
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    n_reg[1] = 0
+    down = rng.integers(0, 2 * n_s_max, (B, n_t, r_max)) * 0.5
+    down[2] += 3.0 * n_s_max                      # far ahead of every cell
+    down[3] = -rng.integers(1, 60, (n_t, r_max)) * 0.5   # behind every cell
+    up = down + rng.integers(0, 12, (B, n_t, r_max)) * 0.5
+    cur = rng.integers(0, 10, B).astype(np.float64)
+    out = mb.st_dp(n_s, down, up, n_reg, cur, LIM)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
+        n = n_s[b]
+        same(out["cost"][b, :, :n].cpu().numpy(), ref["cost"], "cost[%d]" % b)
+        same(out["pre"][b, :, :n].cpu().numpy(), ref["pre"], "pre[%d]" % b)
+        plen = int(out["path_len"][b])
+        assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"])
+
+
 def test_st_other_grid_steps(oracle):
     """ds/dt other than the defaults go through the same tables."""
     import torch
