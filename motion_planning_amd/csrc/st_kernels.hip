@@ -114,6 +114,7 @@ struct StCellLds {
 struct StSh {
     double *cost_prev, *cost_cur, *front, *speed, *acc, *jerk2, *jerk3, *down, *up;
     short *pre16;
+    int *hist; // [N], per predecessor p of the current layer: (pp - 2p) in the low half, (3pp - ppp - 3p) in the high half
 };
 
 // All cells of time layer i >= 2 owned by this thread.
@@ -180,7 +181,7 @@ struct StTab {
 __host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t)
 {
     size_t b = ((size_t)12 * N + 2 * r_max + n_t + 8) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
-               2 * sizeof(int);
+               (2 + (size_t)N) * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -203,8 +204,6 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const double ds = a.ds;
-    const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
-    const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
     const int n1 = n_s - 1;
     // (tb.quiet[] was set to "never" before the barrier in front of this call)
     const double front_step = sh.front[n_s > 1 ? 1 : 0];
@@ -272,14 +271,11 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 else obv = cell.ob(s, sh.front[d]);
                 const double base = __dadd_rn(obv, sh.speed[d]);
                 if (cell.monotone && d >= d_lim && bp != 0x7fffffff && __dadd_rn(base, m_prev) > best) break;
-                const int pp = pre1[p];
-                const int n = d - (p - pp);
-                double jc;
-                if (i == 2) jc = sh.jerk2[n + n1];
-                else {
-                    const int ppp = pre2[pp];
-                    jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * n1];
-                }
+                // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136):
+                // what depends on p alone was looked up once for the layer
+                const int h = sh.hist[p];
+                const int n = j + (int)(short)(h & 0xffff);
+                const double jc = (i == 2) ? sh.jerk2[n + n1] : sh.jerk3[j + (h >> 16) + 2 * n1];
                 const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n1]), jc);
                 const double c = __dadd_rn(tot, sh.cost_prev[p]);
                 if (c <= best) { best = c; bp = p; }
@@ -299,7 +295,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 
 // One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
 //   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
-//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim
+//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim | hist[N] i32
+//   | cell tables dn[r_tab][N] cst[r_tab][N] | quiet[N] i32
 __global__ void st_dp_kernel(StDev a)
 {
     extern __shared__ double smem[];
@@ -326,6 +323,7 @@ __global__ void st_dp_kernel(StDev a)
     double *red = last_col + n_t;
     sh.pre16 = (short *)(red + 8);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
+    sh.hist = d_lim_sh + 2;
     StTab tb; // placed by offset from smem so the pointers stay LDS pointers
     const size_t tab_off = st_tab_offset(N, R_max, n_t);
     tb.dn = smem + tab_off / 8;
@@ -399,6 +397,14 @@ __global__ void st_dp_kernel(StDev a)
             sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
         }
         for (int j = tid; j < n_s; j += nt) tb.quiet[j] = 0x7fffffff;
+        if (i >= 2) {
+            // the predecessor chain of every cell of the layer below (final since the last barrier)
+            for (int p = tid; p < n_s; p += nt) {
+                const int pp = sh.pre16[(size_t)(i - 1) * N + p];
+                const int ppp = sh.pre16[(size_t)(i - 2) * N + pp];
+                sh.hist[p] = ((pp - 2 * p) & 0xffff) | ((3 * pp - ppp - 3 * p) << 16);
+            }
+        }
         if (i + 1 < n_t) {
             R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
             if (tid < R_next) {
