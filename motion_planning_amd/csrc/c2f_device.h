@@ -9,9 +9,8 @@
 // distances sqrt(dx^2 + dy^2) to the M samples (tx, ty), found without a square
 // root per sample; then the sign of the lateral offset from the heading at that
 // sample and the arc length from the table.  Returns the sample index.
-__device__ __forceinline__ int c2f_point(const double *tx, const double *ty, const double *ts,
-                                         const double *tth, int M, double x, double y, double *s_out,
-                                         double *l_out)
+__device__ __forceinline__ int c2f_nearest(const double *tx, const double *ty, int M, double x, double y,
+                                           double *dist_out)
 {
     // sqrt is monotone, so the smallest distance is the root of the smallest squared
     // distance m2, and the first sample that reaches it is the first one whose squared
@@ -56,11 +55,43 @@ __device__ __forceinline__ int c2f_point(const double *tx, const double *ty, con
             if (d2 <= top) k = i;
         }
     }
-    const double th = tth[k];
+    *dist_out = best;
+    return k;
+}
+
+// The whole conversion of one point; (cth, sth) = cos and sin of the heading at the
+// nearest sample.
+__device__ __forceinline__ void c2f_finish(const double *tx, const double *ty, const double *ts, int k,
+                                           double best, double cth, double sth, double x, double y,
+                                           double *s_out, double *l_out)
+{
     const double dx = x - tx[k], dy = y - ty[k];
-    const double l_sign = (dy * cos(th) - dx * sin(th) > 0) ? 1.0 : -1.0;
+    const double l_sign = (dy * cth - dx * sth > 0) ? 1.0 : -1.0;
     *s_out = ts[k];
     *l_out = l_sign * best;
+}
+
+__device__ __forceinline__ int c2f_point(const double *tx, const double *ty, const double *ts,
+                                         const double *tth, int M, double x, double y, double *s_out,
+                                         double *l_out)
+{
+    double best;
+    const int k = c2f_nearest(tx, ty, M, x, y, &best);
+    const double th = tth[k];
+    c2f_finish(tx, ty, ts, k, best, cos(th), sin(th), x, y, s_out, l_out);
+    return k;
+}
+
+// The same with cos / sin of every sample's heading tabulated by the caller (cos_t[k] =
+// cos(tth[k]), sin_t[k] = sin(tth[k]): the same functions on the same arguments, so the
+// same bits), for kernels that convert many points against one line.
+__device__ __forceinline__ int c2f_point_tab(const double *tx, const double *ty, const double *ts,
+                                             const double *cos_t, const double *sin_t, int M, double x,
+                                             double y, double *s_out, double *l_out)
+{
+    double best;
+    const int k = c2f_nearest(tx, ty, M, x, y, &best);
+    c2f_finish(tx, ty, ts, k, best, cos_t[k], sin_t[k], x, y, s_out, l_out);
     return k;
 }
 

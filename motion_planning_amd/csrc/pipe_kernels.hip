@@ -259,11 +259,16 @@ __global__ void plan_frontend_kernel(FrontDev a)
         }
         return;
     }
-    double *tx = smem, *ty = smem + m_max;
+    double *tx = smem, *ty = smem + m_max, *cos_t = smem + 2 * m_max, *sin_t = smem + 3 * m_max;
     const size_t tb = (size_t)b * m_max;
     for (int k = tid; k < M; k += nt) {
         tx[k] = a.o.tab_x[tb + k];
         ty[k] = a.o.tab_y[tb + k];
+        // heading of every sample: a few hundred evaluations per scene instead of one
+        // per obstacle frame
+        const double th = a.o.tab_theta[tb + k];
+        cos_t[k] = cos(th);
+        sin_t[k] = sin(th);
     }
     if (tid == 0) base_sh = 0;
     __syncthreads();
@@ -321,7 +326,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
                     y = a.in.dy_pos[2 * (q * F + f) + 1];
                     rad = a.in.dy_rad[q];
                 }
-                c2f_point(tx, ty, ts, tth, M, x, y, &s, &l);
+                c2f_point_tab(tx, ty, ts, cos_t, sin_t, M, x, y, &s, &l);
                 keep = fabs(l) - rad < a.l_width; // check_in_line (sl_map.py:111-112)
                 if (keep) r_loc = rad > r_loc ? rad : r_loc;
             }
@@ -538,7 +543,7 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
         f.l_start = 0.0 - (p.l_width - p.save_width) / 2.0; // sl_map.py:71-72
         f.l_stop = 0.0 + (p.l_width - p.save_width) / 2.0;
         f.l_step = d.n_l > 1 ? (f.l_stop - f.l_start) / (double)(d.n_l - 1) : 0.0;
-        const size_t lds = (size_t)2 * d.m_max * sizeof(double);
+        const size_t lds = (size_t)4 * d.m_max * sizeof(double);
         if (lds > 64 * 1024) { mp_set_error("m_max too large"); return MP_E_UNSUPPORTED; }
         const int n_slot = d.n_st_max + d.n_dy_max * d.n_frames;
         int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);
