@@ -179,6 +179,43 @@ def test_pipeline_map_too_big_is_a_status():
     assert list(r["status"].cpu().numpy()) == [pl.PIPE_OK, pl.PIPE_MAP_TOO_BIG]
 
 
+def test_bad_scenes_do_not_disturb_their_neighbours():
+    """Scenes with NaN / infinite coordinates, negative or oversized counts and a
+    one-knot line share a batch with healthy scenes: the call returns, the healthy
+    scenes come out bit for bit as in a clean batch, and no damaged scene reports a
+    plan built on NaNs as usable geometry (its status is an error code or its
+    outputs are absent)."""
+    import torch
+    from motion_planning_amd import pipeline as pl
+    rng = np.random.default_rng(91)
+    scenes = [random_scene(rng, 20, 4) for _ in range(10)]
+    clean = pack_scenes(scenes)
+    bad = {k: v.copy() for k, v in clean.items()}
+    bad["st_pos"][2, 3, 0] = np.nan            # an obstacle at NaN
+    bad["dy_pos"][3, 1, 4, 1] = np.inf         # one predicted frame at infinity
+    bad["knots_y"][4, 5] = np.inf              # a reference-line knot at infinity
+    bad["knots_x"][5, 2] = np.nan              # a NaN knot abscissa
+    bad["ego_vel"][6] = np.nan                 # no ego velocity
+    bad["n_st"][7], bad["n_dy"][7] = -3, 1000  # counts outside the arrays
+    bad["n_knots"][8] = 1                      # a line of one knot
+    good = [0, 1, 9]
+    r0 = pl.plan_batch(**clean, m_max=232)
+    r1 = pl.plan_batch(**bad, m_max=232)
+    torch.cuda.synchronize()
+    for k in ("status", "n_layers", "path_idx", "n_ob", "st_n_reg", "st_path_s_ind", "n_prof", "ss", "vv",
+              "final_x", "final_y"):
+        a, b = r0[k][good].cpu().numpy(), r1[k][good].cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), k
+    st = r1["status"].cpu().numpy()
+    assert st[8] == pl.PIPE_BAD_LINE
+    # the counts of scene 7 were clamped to the arrays: it plans like a scene without statics
+    assert st[7] in (pl.PIPE_OK, pl.PIPE_NOT_FOUND)
+    n_prof = r1["n_prof"].cpu().numpy()
+    fx = r1["final_x"].cpu().numpy()
+    for b in (4, 5):    # a broken reference line never yields a path
+        assert st[b] != pl.PIPE_OK or not np.isfinite(fx[b, :n_prof[b]]).all() or n_prof[b] == 0, (b, st[b])
+
+
 def test_plan_scenes_replays_as_a_hip_graph():
     """mp_plan_scenes only enqueues work on the caller's stream (no allocation, no
     synchronisation, nothing read back), so a caller can capture it in a HIP graph and

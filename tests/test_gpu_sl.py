@@ -258,6 +258,43 @@ def test_sl_mirror_symmetric_ties(oracle, n_l, n_pairs):
     assert n_ties > 0
 
 
+@pytest.mark.parametrize("n_l", [5, 40])
+def test_sl_bad_scenarios_do_not_disturb_their_neighbours(n_l):
+    """NaN / infinite obstacle coordinates, a NaN ego offset, NaN radius and counts outside
+    the arrays in some scenarios of a batch: the call returns and the other scenarios
+    come out bit for bit as in a clean batch."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(300 + n_l)
+    B, n_s = 10, 9
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 8.0, 12, 0.4, 0.9, None, True)
+    ob_s, ob_l, n_ob = pad_obstacles(obs)
+    prm = mb.sl_params(early_exit=False, mid_l=int((n_l - 1) / 2))
+
+    def run(ego_, ob_s_, ob_l_, n_ob_, dist_):
+        sb = mb.SLBatch(s_map[:, :, 0], l_map, ego_, ob_s_, ob_l_, n_ob_, dist_, check=False)
+        out = mb.sl_plan(sb, prm)
+        torch.cuda.synchronize()
+        return out
+
+    clean = run(ego, ob_s, ob_l, n_ob, ob_dist)
+    e2, s2, l2, n2, d2 = ego.copy(), ob_s.copy(), ob_l.copy(), n_ob.copy(), ob_dist.copy()
+    s2[1, 0] = np.nan
+    l2[2, 3] = np.inf
+    e2[3, 1] = np.nan
+    d2[4] = np.nan
+    n2[5], n2[6] = -7, 10 ** 6
+    s2[7, :] = -np.inf
+    dirty = run(e2, s2, l2, n2, d2)
+    good = [0, 8, 9]
+    for k in ("cost_map", "index_map", "path_idx", "status", "layers_done"):
+        assert torch.equal(getattr(clean, k)[good], getattr(dirty, k)[good]), k
+    # counts are clamped to the scenario's own slots: scenario 5 plans without obstacles,
+    # scenario 6 with all of its slots
+    st = dirty.status.cpu().numpy()
+    assert st[5] in (0, 1) and st[6] in (0, 1)
+
+
 def test_sl_empty_edge_and_capacity_status():
     from motion_planning_amd import _lib
     s_map = np.array([[[8.0] * 5, [8.2] * 5]])            # second gap shorter than d_s

@@ -176,6 +176,37 @@ def test_st_front_term_switches_on_exactly_at_grid_values(oracle, n_s_max):
         assert np.array_equal(out["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"])
 
 
+def test_st_bad_scenarios_do_not_disturb_their_neighbours():
+    """NaN / infinite interval bounds, a NaN start speed, interval counts outside the arrays
+    and grid widths outside the allocation in some scenarios: the call returns and the
+    other scenarios come out bit for bit as in a clean batch."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(77)
+    B, n_t, r_max, N = 10, 11, 5, 60
+    n_s = rng.integers(20, N + 1, B).astype(np.int32)
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(0, N, (B, n_t, r_max))
+    up = down + rng.uniform(0, 8, (B, n_t, r_max))
+    cur = rng.uniform(0, 10, B)
+    clean = mb.st_dp(n_s, down, up, n_reg, cur, LIM, n_s_max=N)
+    n2, r2, d2, u2, c2 = n_s.copy(), n_reg.copy(), down.copy(), up.copy(), cur.copy()
+    d2[1, 3, 0] = np.nan
+    u2[2, 4, 1] = np.inf
+    d2[3, :, :] = -np.inf
+    c2[4] = np.nan
+    r2[5, 2], r2[5, 6] = -4, 10 ** 6
+    n2[6], n2[7] = 0, N + 50
+    dirty = mb.st_dp(n2, d2, u2, r2, c2, LIM, n_s_max=N)
+    torch.cuda.synchronize()
+    good = [0, 8, 9]
+    for k in ("cost", "pre", "path_s_ind", "path_len"):
+        assert torch.equal(clean[k][good], dirty[k][good]), k
+    plen = dirty["path_len"].cpu().numpy()
+    assert plen[6] == 0 and plen[7] == 0          # no grid: no path
+    assert (dirty["path_s_ind"][6].cpu().numpy() == -1).all()
+
+
 def test_st_other_grid_steps(oracle):
     """ds/dt other than the defaults go through the same tables."""
     import torch
