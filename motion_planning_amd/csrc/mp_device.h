@@ -38,6 +38,7 @@ __device__ __forceinline__ double dpp_all_f64(double v)
 
 #define MP_DPP_QUAD_1032 0xB1   // quad_perm [1,0,3,2]: lane ^ 1
 #define MP_DPP_QUAD_2301 0x4E   // quad_perm [2,3,0,1]: lane ^ 2
+#define MP_DPP_QUAD_3210 0x1B   // quad_perm [3,2,1,0]: lane ^ 3
 #define MP_DPP_HALF_MIRROR 0x141 // lane k <-> 7-k inside each group of 8
 #define MP_DPP_MIRROR 0x140      // lane k <-> 15-k inside each row of 16
 
@@ -84,6 +85,60 @@ __device__ __forceinline__ void group_argmin(double &c, int &i)
         double oc = __shfl_xor(c, m, MP_WAVE);
         int oi = __shfl_xor(i, m, MP_WAVE);
         argmin_merge(c, i, oc, oi);
+    }
+}
+
+// First-minimum (cost, index) of 8 rows at once: on entry every lane holds its own
+// candidate of each of the 8 rows; on return lane k holds, in (rc, ri), the wave-wide
+// result of row k & 7.  The first three steps halve the rows a lane is responsible for
+// (a lane keeps the rows whose index bit equals its own lane bit and hands the others to
+// its partner), so the 8 rows cost about a quarter of 8 separate wave reductions.
+// Every lane of the wave must be active.
+__device__ __forceinline__ void wave_argmin_rows8(const double (&c)[8], const int (&i)[8], double &rc, int &ri)
+{
+    const int lane = threadIdx.x & (MP_WAVE - 1);
+    double c4[4], c2[2];
+    int i4[4], i2[2];
+    {
+        const bool up = lane & 1; // partner: lane ^ 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { // rows 2q (kept by even lanes) and 2q+1 (kept by odd lanes)
+            const double send_c = up ? c[2 * q] : c[2 * q + 1];
+            const int send_i = up ? i[2 * q] : i[2 * q + 1];
+            c4[q] = up ? c[2 * q + 1] : c[2 * q];
+            i4[q] = up ? i[2 * q + 1] : i[2 * q];
+            argmin_merge(c4[q], i4[q], dpp_all_f64<MP_DPP_QUAD_1032>(send_c), dpp_all_i32<MP_DPP_QUAD_1032>(send_i));
+        }
+    }
+    {
+        const bool up = lane & 2; // partner: lane ^ 2; c4[q] is row 2q + (lane & 1)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { // c4[2q] (row bit 1 clear) and c4[2q+1] (row bit 1 set)
+            const double send_c = up ? c4[2 * q] : c4[2 * q + 1];
+            const int send_i = up ? i4[2 * q] : i4[2 * q + 1];
+            c2[q] = up ? c4[2 * q + 1] : c4[2 * q];
+            i2[q] = up ? i4[2 * q + 1] : i4[2 * q];
+            argmin_merge(c2[q], i2[q], dpp_all_f64<MP_DPP_QUAD_2301>(send_c), dpp_all_i32<MP_DPP_QUAD_2301>(send_i));
+        }
+    }
+    {
+        const bool up = lane & 4; // partner: lane ^ 4 = half mirror, then the quad reversed
+        const double send_c = up ? c2[0] : c2[1];
+        const int send_i = up ? i2[0] : i2[1];
+        rc = up ? c2[1] : c2[0];
+        ri = up ? i2[1] : i2[0];
+        argmin_merge(rc, ri, dpp_all_f64<MP_DPP_QUAD_3210>(dpp_all_f64<MP_DPP_HALF_MIRROR>(send_c)),
+                     dpp_all_i32<MP_DPP_QUAD_3210>(dpp_all_i32<MP_DPP_HALF_MIRROR>(send_i)));
+    }
+    // lane k now holds row k & 7 over its group of 8 lanes; the groups are merged as they are
+    // lane ^ 8 = row mirror, then half mirror
+    argmin_merge(rc, ri, dpp_all_f64<MP_DPP_HALF_MIRROR>(dpp_all_f64<MP_DPP_MIRROR>(rc)),
+                 dpp_all_i32<MP_DPP_HALF_MIRROR>(dpp_all_i32<MP_DPP_MIRROR>(ri)));
+#pragma unroll
+    for (int m = 16; m < MP_WAVE; m <<= 1) {
+        const double oc = __shfl_xor(rc, m, MP_WAVE);
+        const int oi = __shfl_xor(ri, m, MP_WAVE);
+        argmin_merge(rc, ri, oc, oi);
     }
 }
 

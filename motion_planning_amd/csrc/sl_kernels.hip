@@ -1125,6 +1125,8 @@ __device__ __forceinline__ double block_min(double v, double *red)
     return r;
 }
 
+#define SL_DP_ROWS 8 // target rows whose loads a wave issues together
+
 // DP relaxation over a materialised edge-cost tensor.  One workgroup per
 // scenario; each wave owns target rows, its 64 lanes stride over the sources
 // (coalesced reads) and the row's first-minimum is found with a wave-level
@@ -1161,6 +1163,40 @@ __global__ void sl_dp_kernel(int n_sm, int n_l, const int32_t *n_layers, const d
             for (int l = tid; l < n_l; l += nt) {
                 cost_cur[l] = el[(size_t)l * n_l];
                 imap[l] = -1;
+            }
+        } else if ((n_l & 1) == 0 && n_l <= 2 * MP_WAVE) {
+            // Rows of up to 128 sources, 16-byte aligned: a lane holds the sources 2*lane and
+            // 2*lane+1 of a row (one 16-byte load), and the loads of SL_DP_ROWS rows are issued
+            // before the first of them is reduced, so that a wave has that many kilobytes in
+            // flight instead of one row at a time.
+            const int pj = 2 * lane;
+            const bool has = pj < n_l;
+            const double cp0 = has ? cost_prev[pj] : 0.0, cp1 = has ? cost_prev[pj + 1] : 0.0;
+            for (int l0 = wave; l0 < n_l; l0 += nw * SL_DP_ROWS) {
+                double2 e[SL_DP_ROWS];
+#pragma unroll
+                for (int q = 0; q < SL_DP_ROWS; ++q) {
+                    const int l2 = l0 + q * nw;
+                    e[q] = make_double2(MP_INF, MP_INF);
+                    if (has && l2 < n_l) e[q] = *(const double2 *)(el + (size_t)l2 * n_l + pj);
+                }
+                double c[SL_DP_ROWS];
+                int i[SL_DP_ROWS];
+#pragma unroll
+                for (int q = 0; q < SL_DP_ROWS; ++q) { // rows past the end hold +inf: harmless
+                    const double v0 = e[q].x + cp0, v1 = e[q].y + cp1;
+                    const bool second = v1 < v0;
+                    c[q] = has ? (second ? v1 : v0) : MP_INF;
+                    i[q] = has ? (second ? pj + 1 : pj) : 0x7fffffff;
+                }
+                double rc;
+                int ri;
+                wave_argmin_rows8(c, i, rc, ri);
+                const int l2 = l0 + lane * nw; // lane q < 8 holds row q of the batch
+                if (lane < SL_DP_ROWS && l2 < n_l) {
+                    cost_cur[l2] = rc;
+                    imap[(size_t)s * n_l + l2] = ri;
+                }
             }
         } else {
             for (int l2 = wave; l2 < n_l; l2 += nw) {
