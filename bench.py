@@ -305,6 +305,44 @@ def cpu_baseline(sc, n_sample, threads):
     return n_sample / dt, dt
 
 
+def materialised_roofline(sc, n, prm):
+    """The two-kernel form of the same SL plan on the first n scenarios, outside the timed
+    region: mp_sl_edge_cost writes every edge cost to HBM (fp64, 8 B/edge) and mp_sl_dp
+    streams that tensor once -- the HBM-bound relaxation the fused kernel makes unnecessary,
+    measured so that an HBM roofline fraction below 1 is on record."""
+    import torch
+    from motion_planning_amd import batch as mb
+    sb = mb.SLBatch(sc["s_layers"][:n], sc["l_row"][:n], sc["ego"][:n], sc["ob_s"][:n], sc["ob_l"][:n],
+                    sc["n_ob"][:n], sc["ob_dist"][:n])
+    edge, _ = mb.sl_edge_cost(sb, prm)
+    out = mb.sl_dp(edge, prm)
+    fused = mb.sl_plan(sb, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(out.path_idx, fused.path_idx) and torch.equal(out.status, fused.status)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    reps, t_e, t_d = 3, 0.0, 0.0
+    for _ in range(reps):
+        ev[0].record()
+        edge, _ = mb.sl_edge_cost(sb, prm)
+        ev[1].record()
+        mb.sl_dp(edge, prm, out=out)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_e += ev[0].elapsed_time(ev[1]) / reps
+        t_d += ev[1].elapsed_time(ev[2]) / reps
+    nbytes = 8.0 * n * N_S * N_L * N_L
+    gbs = nbytes / (t_d * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "sl_dp_kernel (relaxation over the materialised fp64 edge tensor)",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel_ms": t_d, "algorithmic_bytes_per_launch": nbytes, "scenarios": n,
+            "edge_kernel": {"kernel": "sl_edge_cost_kernel", "kernel_ms": t_e,
+                            "written_GBps": nbytes / (t_e * 1e-3) / 1e9,
+                            "edges_per_sec": n * N_S * N_L * N_L / (t_e * 1e-3)},
+            "note": "not part of the timed step: the product path is the fused kernel (roofline / roofline_other); "
+                    "this is the same plan through mp_sl_edge_cost + mp_sl_dp, whose DP kernel reads each edge "
+                    "cost once from HBM"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +355,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=448, help="scenarios timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--early-exit", type=int, default=0, help="1 = stop a scenario at its first failing layer")
+    ap.add_argument("--materialised", type=int, default=1024,
+                    help="scenarios run through the two-kernel SL path for its HBM roofline (0 = skip)")
     ap.add_argument("--maps", type=int, default=0, help="1 = also write cost_map/index_map/ST tables to HBM")
     args = ap.parse_args()
 
@@ -469,6 +509,8 @@ def main():
             "roofline_other": roof_st if dominant is roof_sl else roof_sl,
             "pmc_source": pmc.get("_source"),
         }
+        if args.materialised > 0:
+            res["roofline_materialised"] = materialised_roofline(sc, min(args.materialised, B), prm)
         if args.cpu_sample > 0:
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             v, dt = cpu_baseline(sc, min(args.cpu_sample, B), threads)

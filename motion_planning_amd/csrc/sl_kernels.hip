@@ -1100,6 +1100,22 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     Collider<-2> col_all;
     col_list.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
     col_all.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+    if (n_src == n_l && nt % n_l == 0) {
+        // the workgroup's size is a multiple of the row length: a thread keeps one source
+        // for all of its edges, and what depends on the source alone leaves the loop
+        const int j = tid % n_l;
+        const double l1 = lprev_g[j];
+        const double u = l1 - mid;
+        const double g = guide_straight(u, geo.K, w_d, d_s), ua = 2.0 * cG * A * u;
+        for (int l2 = tid / n_l; l2 < n_l; l2 += nt / n_l) {
+            const double dl = lcur_g[l2] - l1;
+            double c = edge_closed_form(dl, g, ua, Q);
+            const bool hit = n_ent <= SL_E_CAP ? col_list.hit(l1, dl) : col_all.hit(l1, dl);
+            c += hit ? pen : 0.0;
+            out[(size_t)l2 * n_l + j] = c;
+        }
+        return;
+    }
     for (int e = tid; e < n_l * n_l; e += nt) {
         const int l2 = e / n_l, j = e - l2 * n_l;
         if (j >= n_src) { out[e] = __builtin_nan(""); continue; }
