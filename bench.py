@@ -332,8 +332,14 @@ def materialised_roofline(sc, n, prm):
         t_d += ev[1].elapsed_time(ev[2]) / reps
     nbytes = 8.0 * n * N_S * N_L * N_L
     gbs = nbytes / (t_d * 1e-3) / 1e9
+    # counters of the committed passes were taken on the default sample (1024 scenarios); the
+    # kernel reads 16 bytes per lane, for which FETCH_SIZE on gfx950 reports half of the bytes
+    k = load_pmc().get("sl_dp_kernel", {})
+    traffic = None
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k and n == 1024:
+        traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
     return {"bound": "hbm", "kernel": "sl_dp_kernel (relaxation over the materialised fp64 edge tensor)",
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": t_d, "algorithmic_bytes_per_launch": nbytes, "scenarios": n,
             "edge_kernel": {"kernel": "sl_edge_cost_kernel", "kernel_ms": t_e,
                             "written_GBps": nbytes / (t_e * 1e-3) / 1e9,
