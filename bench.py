@@ -316,9 +316,10 @@ def materialised_roofline(sc, n, prm):
                     sc["n_ob"][:n], sc["ob_dist"][:n])
     edge, _ = mb.sl_edge_cost(sb, prm)
     out = mb.sl_dp(edge, prm)
-    fused = mb.sl_plan(sb, prm)
     torch.cuda.synchronize()
-    assert torch.equal(out.path_idx, fused.path_idx) and torch.equal(out.status, fused.status)
+    # (the tests compare this path with the fused kernel bit for bit; launching the fused
+    # kernel here would mix a launch of another size into its per-kernel profile)
+    assert torch.equal(out.path_idx[:, 0] >= 0, out.status == 1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     reps, t_e, t_d = 3, 0.0, 0.0
     for _ in range(reps):
