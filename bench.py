@@ -256,7 +256,7 @@ def bench_pipeline(args, world, rank, backend):
                              "from LDS-resident tables, so the chain is bound by instruction issue and latency, "
                              "not by HBM"},
     }
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         n = min(args.cpu_sample, B)
         v, dt = cpu_pipeline(sc, n, threads)
@@ -516,9 +516,9 @@ def main():
             "roofline_other": roof_st if dominant is roof_sl else roof_sl,
             "pmc_source": pmc.get("_source"),
         }
-        if args.materialised > 0:
+        if args.materialised > 0 and world == 1:
             res["roofline_materialised"] = materialised_roofline(sc, min(args.materialised, B), prm)
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             v, dt = cpu_baseline(sc, min(args.cpu_sample, B), threads)
             res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
