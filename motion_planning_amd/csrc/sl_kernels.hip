@@ -1100,6 +1100,26 @@ __global__ void sl_edge_cost_kernel(SlDev a)
     Collider<-2> col_all;
     col_list.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
     col_all.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+    if (n_src == n_l && (n_l & 1) == 0 && (2 * nt) % n_l == 0 && n_l <= 2 * nt) {
+        // two neighbouring sources per thread, kept for all of its edges: what depends on the
+        // source alone leaves the loop and a thread stores 16 bytes per target row
+        const int hp = n_l / 2, jp = tid % hp, j = 2 * jp;
+        const double l1a = lprev_g[j], l1b = lprev_g[j + 1];
+        const double ua = l1a - mid, ub = l1b - mid;
+        const double ga = guide_straight(ua, geo.K, w_d, d_s), gb = guide_straight(ub, geo.K, w_d, d_s);
+        const double xa = 2.0 * cG * A * ua, xb = 2.0 * cG * A * ub;
+        for (int l2 = tid / hp; l2 < n_l; l2 += nt / hp) {
+            const double l2v = lcur_g[l2];
+            const double dla = l2v - l1a, dlb = l2v - l1b;
+            double ca = edge_closed_form(dla, ga, xa, Q), cb = edge_closed_form(dlb, gb, xb, Q);
+            const bool ha = n_ent <= SL_E_CAP ? col_list.hit(l1a, dla) : col_all.hit(l1a, dla);
+            const bool hb = n_ent <= SL_E_CAP ? col_list.hit(l1b, dlb) : col_all.hit(l1b, dlb);
+            ca += ha ? pen : 0.0;
+            cb += hb ? pen : 0.0;
+            *(double2 *)(out + (size_t)l2 * n_l + j) = make_double2(ca, cb);
+        }
+        return;
+    }
     if (n_src == n_l && nt % n_l == 0) {
         // the workgroup's size is a multiple of the row length: a thread keeps one source
         // for all of its edges, and what depends on the source alone leaves the loop
