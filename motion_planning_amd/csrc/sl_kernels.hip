@@ -522,8 +522,9 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 // grid changes from layer to layer (that row is prefetched a layer ahead).
 // Dynamic LDS layout (n_lp = n_l rounded up to even, cap = pair_cap):
 //   lc[2][n_lp] double2 | layA layQ layW layP2 layMid [n_s] each | pairs[3][cap] (basis value,
-//   obstacle offset, squared arc-length gap) | red[2][8] | layK[n_s] int (K, bit 16: end point
-//   appended) | cntL[n_s] int (pairs per layer) | offL[n_s] u16 (first pair of the layer)
+//   obstacle offset, squared arc-length gap) | red[2][8] redmax[8] | layK[n_s] int (K, bit 16: end
+//   point appended) | cntL[n_s] int (pairs per layer) | excL[n_s] int, first_ex[2] int (abort
+//   bookkeeping of layers without a barrier) | offL[n_s] u16 (first pair of the layer)
 //   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
 __global__ void sl_plan_kernel(SlDev a)
 {
@@ -542,9 +543,12 @@ __global__ void sl_plan_kernel(SlDev a)
     double *layMid = layP2 + n_sm;
     double *pair_h0 = layMid + n_sm, *pair_ol = pair_h0 + cap, *pair_ds2 = pair_ol + cap;
     double *red = pair_ds2 + cap;
-    int *layK = (int *)(red + 16);
+    double *redmax = red + 16;
+    int *layK = (int *)(redmax + 8);
     int *cntL = layK + n_sm;
-    unsigned short *offL = (unsigned short *)(cntL + n_sm);
+    int *excL = cntL + n_sm;      // per layer: waves whose targets all exceed the abort threshold
+    int *first_ex = excL + n_sm;  // first layer every wave reported (2 ints, keeps what follows aligned)
+    unsigned short *offL = (unsigned short *)(first_ex + 2);
     unsigned char *laySorted = (unsigned char *)(offL + n_sm + (n_sm & 1));
     unsigned char *idx8 = laySorted + ((n_sm + 3) & ~3);
 
@@ -578,6 +582,7 @@ __global__ void sl_plan_kernel(SlDev a)
         layMid[s] = lbase[(size_t)s * rstride + mid_l];
         laySorted[s] = 1;
         cntL[s] = 0;
+        excL[s] = 0;
         if (g.K >= 0) {
             const LayerConst c = layer_const(g, p1s, p2s, d_s, cG, cS);
             layA[s] = c.A;
@@ -591,7 +596,7 @@ __global__ void sl_plan_kernel(SlDev a)
     {
         // largest |l - mid| over the lattice (bounds every straight-edge cost)
         // and, per lattice row, whether it ascends
-        double u_loc = 0.0;
+        double u_loc = 0.0, gap_loc = MP_INF; // gap_loc: smallest spacing of neighbouring lanes (row 0)
         const int rows = rstride ? n_s : 1;
         for (int i = tid; i < rows * n_l; i += nt) {
             const int row = i / n_l, col = i - row * n_l;
@@ -600,11 +605,20 @@ __global__ void sl_plan_kernel(SlDev a)
             const double u = fabs(v - lr[mid_l]);
             u_loc = u > u_loc ? u : u_loc;
             if (col > 0 && !(lr[col - 1] <= v)) laySorted[row] = 0;
+            if (row == 0 && col > 0) {
+                const double gp = v - lr[col - 1];
+                gap_loc = gp < gap_loc ? gp : gap_loc;
+            }
         }
         const double u_ego = fabs(ego_l - layMid[n_s - 1]);
         u_loc = u_ego > u_loc ? u_ego : u_loc;
         u_loc = -wave_min_f64(-u_loc);
-        if ((tid & (MP_WAVE - 1)) == 0) red[wave] = u_loc;
+        gap_loc = wave_min_f64(gap_loc);
+        if ((tid & (MP_WAVE - 1)) == 0) {
+            red[wave] = u_loc;
+            redmax[wave] = gap_loc;
+        }
+        if (tid == 0) first_ex[0] = 0x7fffffff;
     }
     // ---- prologue: the (sample, obstacle) pairs of every layer --------------------
     PairStore ps;
@@ -621,7 +635,21 @@ __global__ void sl_plan_kernel(SlDev a)
     double u_max = red[0];
     for (int w = 1; w < nw; ++w) u_max = red[w] > u_max ? red[w] : u_max;
     const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
-    __syncthreads(); // red is reused by the layer loop
+    double gap_min = redmax[0];
+    for (int w = 1; w < nw; ++w) gap_min = redmax[w] < gap_min ? redmax[w] : gap_min;
+    // Layers that need no exchange between lanes.  With one lateral row shared by all layers
+    // (ascending, no two lanes equal) a target's own lane is its first candidate, a straight
+    // edge that costs at most g_max + pen, so after layer s no cost exceeds
+    // c_top(s) = c_top(s-1) + g_max + pen.  The walk of relax_target looks at a neighbour only
+    // if its squared lateral distance is within (best - min + slack) * w_inv <= (c_top + slack)
+    // * w_inv; once that is below the squared lane spacing no target can look at any other
+    // lane: every thread then prices its own straight edge from registers, and the layer needs
+    // neither the other lanes' nodes nor the layer minimum nor a barrier.  (The reference's
+    // absolute-s evaluation makes w_inv fall like s^-8, so this holds from the first few
+    // layers on.)  0 switches the shortcut off.
+    const double gap2_min = (!rstride && n_l > 1 && laySorted[0] && gap_min > 0.0 && gap_min < MP_INF)
+                                ? gap_min * gap_min * (1.0 - 1e-9) : 0.0;
+    __syncthreads(); // red / redmax are reused by the layer loop
 
     const bool is_target = tid < n_l;
     double l_cur = is_target ? lbase[tid] : 0.0; // row 0, this thread's node
@@ -648,10 +676,23 @@ __global__ void sl_plan_kernel(SlDev a)
     };
     load_layer(0, cur);
     double p1s = ego_s;
+    double c_top = MP_INF;  // upper bound of every accumulated cost of the layer being relaxed
+    double cost_own = 0.0;  // this thread's node of the previous layer
+    bool local = false;     // the layer being relaxed needs no exchange between lanes
+    auto is_local = [&](double top, double w_inv_l) {
+        return gap2_min > 0.0 && w_inv_l > 0.0 && (top + 1e-12 * (g_max + top)) * w_inv_l < gap2_min;
+    };
     for (int s = 0; s < n_s; ++s) {
         const int buf = s & 1;
         double m_prev = 0.0; // minimum accumulated cost over the previous layer
-        if (s > 0) {
+        if (s == 1) {
+            // largest cost of layer 0, from which the bound c_top grows
+            double top0 = redmax[0];
+            for (int w = 1; w < nw; ++w) top0 = redmax[w] > top0 ? redmax[w] : top0;
+            c_top = top0 < MP_INF ? (top0 + g_max + pen) * (1.0 + 1e-12) : MP_INF;
+            local = false; // layer 1 still takes the walk (its minimum was reduced with layer 0's)
+        }
+        if (s > 0 && !local) {
             m_prev = red[buf * 8];
             for (int w = 1; w < nw; ++w) m_prev = red[buf * 8 + w] < m_prev ? red[buf * 8 + w] : m_prev;
             if (s >= 2 && m_prev > abort_thr) {
@@ -684,7 +725,25 @@ __global__ void sl_plan_kernel(SlDev a)
         const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
         double best = MP_INF;
         int bj = 0;
-        if (is_target) {
+        if (is_target && local) {
+            // own lane only; the same arithmetic as relax_target's first candidate
+            const double u = l_cur - src.mid;
+            const double dl = l_cur - l_cur;
+            double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
+            bool hit;
+            if (ent_stored) {
+                Collider<-1> col;
+                col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+                hit = col.hit(l_cur, dl);
+            } else {
+                Collider<-2> col;
+                col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
+                hit = col.hit(l_cur, dl);
+            }
+            e += hit ? pen : 0.0;
+            best = e + cost_own;
+            bj = tid;
+        } else if (is_target) {
 #define SL_RELAX(NE)                                                                                     \
     {                                                                                                    \
         Collider<NE> col;                                                                                \
@@ -711,6 +770,8 @@ __global__ void sl_plan_kernel(SlDev a)
                 break;
             }
 #undef SL_RELAX
+        }
+        if (is_target) {
             idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
             const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
@@ -718,12 +779,34 @@ __global__ void sl_plan_kernel(SlDev a)
             // this node as a source of the next layer (after the last layer the
             // row is only read by the end-node search)
             lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
+            cost_own = best;
         }
         done = s + 1;
         if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
-        best = wave_min_f64(best);
-        if ((tid & (MP_WAVE - 1)) == 0) red[(buf ^ 1) * 8 + wave] = best;
-        __syncthreads();
+        if (s >= 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer s + 1
+        const bool next_local = s >= 1 && s + 1 < n_s && is_local(c_top, nxt.w_inv);
+        if (next_local) {
+            // no minimum and no barrier: the abort test of this layer (every cost above the
+            // threshold) is kept as a count of the waves for which it holds
+            if (s >= 1) {
+                const bool all_above = __all(!is_target || best > abort_thr);
+                if (all_above && (tid & (MP_WAVE - 1)) == 0) {
+                    if (atomicAdd(&excL[s], 1) == nw - 1) atomicMin(first_ex, s);
+                }
+            }
+            // a layer that did walk over the other lanes' nodes must be finished by every
+            // wave before the next one overwrites them
+            if (!local) __syncthreads();
+        } else {
+            if (s == 0) {
+                const double top = -wave_min_f64(is_target ? -best : MP_INF);
+                if ((tid & (MP_WAVE - 1)) == 0) redmax[wave] = top;
+            }
+            best = wave_min_f64(best);
+            if ((tid & (MP_WAVE - 1)) == 0) red[(buf ^ 1) * 8 + wave] = best;
+            __syncthreads();
+        }
+        local = next_local;
         l_cur = l_next;
         p1s = p2s;
         cur = nxt;
@@ -736,6 +819,15 @@ __global__ void sl_plan_kernel(SlDev a)
         if (m > abort_thr) status = MP_SL_NOT_FOUND;
     }
     __syncthreads();
+    {
+        // layers that ran without a barrier: the first one whose costs all exceeded the
+        // threshold is where the reference gives up
+        const int s_ex = first_ex[0];
+        if (s_ex != 0x7fffffff && status >= MP_SL_NOT_FOUND) {
+            status = MP_SL_NOT_FOUND;
+            if (a.p.early_exit && s_ex + 1 < done) done = s_ex + 1;
+        }
+    }
     // rows that were never relaxed keep the reference's initial values
     for (int i = done * n_l + tid; i < n_sm * n_l; i += nt) {
         size_t o = (size_t)b * n_sm * n_l + i;
@@ -1311,8 +1403,8 @@ extern void mp_set_error(const char *fmt, ...);
 
 static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
 {
-    size_t d = (size_t)4 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 3 * (size_t)cap + 16;
-    size_t bytes = d * sizeof(double) + 2 * (size_t)n_s * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
+    size_t d = (size_t)4 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 3 * (size_t)cap + 24;
+    size_t bytes = d * sizeof(double) + (3 * (size_t)n_s + 2) * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
     bytes += (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
