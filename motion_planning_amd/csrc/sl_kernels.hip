@@ -244,6 +244,7 @@ struct Collider {
 #define PAIRS_TOO_MANY 0xFFFFu // offL of a layer that alone has more pairs than the store holds
 struct PairStore {
     int n_s, n_ob, cap;
+    bool ascending;                 // ego_s <= layP2[0] <= layP2[1] <= ...
     const double *ob_s, *ob_l;      // obstacles of the scenario (global memory)
     bool has_ob;                    // this thread's first obstacle, held in registers
     double my_os, my_ol;
@@ -279,6 +280,24 @@ struct PairStore {
             if (g.K >= 0) f(s, g, (s == 0) ? ego_s : layP2[s - 1], layP2[s], os, ol_);
         };
         auto one = [&](bool active, double os, double ol_) {
+            if (ascending) {
+                // arc lengths ascend: the layers an obstacle can reach are those from the
+                // first whose end is not below os - rr up to the last whose start is not
+                // above os + rr; the first is found by bisection (the same number of steps
+                // in every lane), the rest by walking on
+                int lo = s_begin, hi = n_s; // first s in [s_begin, n_s) with !(os > layP2[s] + rr)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (os > layP2[mid] + rr) lo = mid + 1; else hi = mid;
+                }
+                if (!active) return;
+                for (int s = lo; s < n_s; ++s) {
+                    const double p1 = (s == 0) ? ego_s : layP2[s - 1];
+                    if (os < p1 - rr) break;
+                    visit(s, os, ol_);
+                }
+                return;
+            }
             int s_first = 0, cnt = 0;
             bool contiguous = true;
             double p1s = (s_begin == 0) ? ego_s : layP2[s_begin - 1];
@@ -573,9 +592,11 @@ __global__ void sl_plan_kernel(SlDev a)
     const double my_os = has_ob ? ob_s[tid] : 0.0, my_ol = has_ob ? ob_l[tid] : 0.0;
 
     // ---- prologue: per-layer constants, one thread per layer ----------------
+    int out_of_order = 0; // a layer that starts after it ends
     for (int s = tid; s < n_s; s += nt) {
         const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
         const double p2s = s_layers[s];
+        out_of_order |= !(p1s <= p2s);
         const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
         layK[s] = g.K < 0 ? g.K : (g.K | ((g.n != g.K) << 16));
         layP2[s] = p2s;
@@ -592,7 +613,7 @@ __global__ void sl_plan_kernel(SlDev a)
             layW[s] = (c.cSH > 0.0 && c.Q <= 1e5 * c.cSH) ? (1.0 + 1e-9) / (c.cSH * (1.0 - 1e-9)) : 0.0;
         }
     }
-    __syncthreads();
+    const bool layers_ascend = !__syncthreads_or(out_of_order);
     {
         // largest |l - mid| over the lattice (bounds every straight-edge cost)
         // and, per lattice row, whether it ascends
@@ -623,6 +644,7 @@ __global__ void sl_plan_kernel(SlDev a)
     // ---- prologue: the (sample, obstacle) pairs of every layer --------------------
     PairStore ps;
     ps.n_s = n_s; ps.n_ob = n_ob; ps.cap = cap;
+    ps.ascending = layers_ascend;
     ps.ob_s = ob_s; ps.ob_l = ob_l;
     ps.has_ob = has_ob; ps.my_os = my_os; ps.my_ol = my_ol;
     ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
@@ -921,9 +943,11 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     const double ego_s = a.in.ego_sl[2 * b], ego_l = a.in.ego_sl[2 * b + 1];
     const int t = tid / W, j = tid - t * W;
 
+    int out_of_order = 0; // a layer that starts after it ends
     for (int s = tid; s < n_s; s += nt) {
         const double p1s = (s == 0) ? ego_s : s_layers[s - 1];
         const double p2s = s_layers[s];
+        out_of_order |= !(p1s <= p2s);
         const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
         layK[s] = g.K < 0 ? g.K : (g.K | ((g.n != g.K) << 16));
         layP2[s] = p2s;
@@ -935,9 +959,10 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
             layQ[s] = c.Q;
         }
     }
-    __syncthreads();
+    const bool layers_ascend = !__syncthreads_or(out_of_order);
     PairStore ps;
     ps.n_s = n_s; ps.n_ob = n_ob; ps.cap = cap;
+    ps.ascending = layers_ascend;
     ps.ob_s = ob_s; ps.ob_l = ob_l;
     ps.has_ob = tid < n_ob;
     ps.my_os = ps.has_ob ? ob_s[tid] : 0.0;
