@@ -161,7 +161,7 @@ def test_sl_random_vs_oracle(oracle, shape, early_exit):
             assert np.array_equal(res[b]["cost_map"], other["cost_map"])
             assert np.array_equal(res[b]["index_map"], other["index_map"])
             assert np.array_equal(res[b]["path_idx"], other["path_idx"])
-            assert res[b]["status"] == other["status"]
+            assert res[b]["status"] == other["status"] and res[b]["layers_done"] == other["layers_done"]
         if small:
             d = ref["layers_done"]
             assert_costs(edges[b, 0, :, 0], ref["edge_cost"][0, :, 0])
@@ -307,6 +307,72 @@ def test_sl_empty_edge_and_capacity_status():
     (r,) = gpu_sl(np.array([[[8.0] * 5, [8.2] * 5]]), l_map, 2, np.zeros((1, 2)), [np.zeros((0, 2))],
                   np.array([0.0]))
     assert r["status"] == _lib.MP_SL_FOUND                  # no obstacles: empty edge costs 0
+
+
+@pytest.mark.parametrize("n_l", [5, 24])
+def test_sl_layers_out_of_order(oracle, n_l):
+    """A layer placed behind its predecessor ends the plan there (an edge without samples
+    next to obstacles, the reference's ValueError), but the layers in front of it are
+    relaxed as usual -- with their obstacle pairs found although the layers' arc lengths
+    do not ascend."""
+    from motion_planning_amd import _lib
+    rng = np.random.default_rng(8 + n_l)
+    B, n_s = 4, 6
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 8.0, 25, 0.4, 0.9, None, False)
+    s_map[1, 3] = 20.0      # layer 3 of scenario 1 lies behind layer 2 (24 m)
+    s_map[2, 1] = 4.0       # layer 1 of scenario 2 lies behind layer 0 (8 m)
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False)
+    # the other fused kernel on the same lattice (lane-per-edge <-> thread-per-node)
+    res_other = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False, per_node=True) if n_l <= 16 else res
+    for b, bad in ((1, 3), (2, 1)):
+        assert res[b]["status"] == _lib.MP_SL_E_EMPTY_EDGE and res[b]["layers_done"] == bad
+        ref = oracle.sl_find_path(s_map[b, :bad], l_map[b, :bad], mid_l, ego[b], obs[b], ob_dist[b],
+                                  no_early_exit=True)
+        assert_costs(res[b]["cost_map"][:bad], ref["cost_map"])
+        assert np.array_equal(res[b]["index_map"][:bad], ref["index_map"])
+        assert (res[b]["index_map"][bad:] == -2).all() and (res[b]["path_idx"] == -1).all()
+    for b in (0, 3):
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b], no_early_exit=True)
+        assert_sl_parity(res[b], ref, None)
+    for b in range(B):
+        assert np.array_equal(res[b]["index_map"], res_other[b]["index_map"])
+        assert np.array_equal(res[b]["cost_map"], res_other[b]["cost_map"]) and res[b]["status"] == res_other[b]["status"]
+
+
+@pytest.mark.parametrize("n_l", [32, 100])
+@pytest.mark.parametrize("early_exit", [True, False])
+def test_sl_wall_far_down_the_lattice(oracle, n_l, early_exit):
+    """Walls of obstacles across every lane, deep in the lattice where a shared lateral
+    row lets the fused kernel relax layers without exchanging nodes or minima: four
+    blocked layers in a row exceed the abort threshold.  Cost map, index map, status and
+    the number of layers relaxed must match the oracle with and without early exit, and
+    the per-layer-row layout (which always takes the walk)."""
+    B, n_s = 6, 24
+    rng = np.random.default_rng(61 + n_l)
+    s_map, l_map, ego, _, ob_dist = random_batch(rng, B, n_s, n_l, 1.5, 1, 0.45, 0.55, None, False)
+    obs = []
+    for b in range(B):
+        first = 10 + 2 * b                      # first walled layer
+        n_wall = [4, 3, 5, 4, 1, 4][b]          # 3 walls stay under the threshold, 4 or more do not
+        wall_l = np.arange(-1.8, 1.81, 0.3)
+        pts = [(1.5 * (k + 1) - 0.05, l) for k in range(first, min(first + n_wall, n_s)) for l in wall_l]
+        pts += [(rng.uniform(1, 12), rng.uniform(-2, 2)) for _ in range(3)]
+        obs.append(np.array(pts))
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit, shared_row=True)
+    res_rows = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=early_exit)
+    n_found = 0
+    for b in range(B):
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b],
+                                  no_early_exit=not early_exit)
+        assert_sl_parity(res[b], ref, None)
+        assert res[b]["layers_done"] == ref["layers_done"], b
+        n_found += ref["found"]
+        for k in ("cost_map", "index_map", "path_idx"):
+            assert np.array_equal(res[b][k], res_rows[b][k]), (b, k)
+        assert res[b]["status"] == res_rows[b]["status"] and res[b]["layers_done"] == res_rows[b]["layers_done"]
+    assert 0 < n_found < B
 
 
 def test_sl_largest_fused_lattice(oracle):
