@@ -22,7 +22,12 @@ def main():
     sc = make_scenarios(0, B)
     if os.environ.get('SL_NO_OB'):   # the same lattice without obstacles: the DP's fixed cost per layer
         sc["n_ob"] = sc["n_ob"] * 0
-    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
+    n_layers = None
+    if os.environ.get('SL_LAYERS'):   # only the first k layers of every scenario: where the time goes
+        import numpy as np
+        n_layers = np.full(B, int(os.environ['SL_LAYERS']), np.int32)
+    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"],
+                    n_layers=n_layers)
     prm = mb.sl_params(early_exit=False, n_l=N_L)
     out = mb.SLPlanOut(B, N_S, N_L, want_maps=False)
     for _ in range(5):
