@@ -698,6 +698,8 @@ __global__ void sl_plan_kernel(SlDev a)
     };
     load_layer(0, cur);
     double p1s = ego_s;
+    int g_K = -1;           // sample count and row centre g_own was computed for
+    double g_mid = 0.0, g_own = 0.0;
     double c_top = MP_INF;  // upper bound of every accumulated cost of the layer being relaxed
     double cost_own = 0.0;  // this thread's node of the previous layer
     bool local = false;     // the layer being relaxed needs no exchange between lanes
@@ -751,7 +753,12 @@ __global__ void sl_plan_kernel(SlDev a)
             // own lane only; the same arithmetic as relax_target's first candidate
             const double u = l_cur - src.mid;
             const double dl = l_cur - l_cur;
-            double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
+            if (geo.K != g_K || src.mid != g_mid) { // the same for all layers of a regular lattice
+                g_K = geo.K;
+                g_mid = src.mid;
+                g_own = guide_straight(u, src.K, src.w_d, src.d_s);
+            }
+            double e = edge_closed_form(dl, g_own, src.two_cga * u, Q);
             bool hit;
             if (ent_stored) {
                 Collider<-1> col;
@@ -793,20 +800,20 @@ __global__ void sl_plan_kernel(SlDev a)
             }
 #undef SL_RELAX
         }
+        done = s + 1;
+        if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
+        if (s >= 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer s + 1
+        const bool next_local = s >= 1 && s + 1 < n_s && is_local(c_top, nxt.w_inv);
         if (is_target) {
             idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
             const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
             if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
-            // this node as a source of the next layer (after the last layer the
-            // row is only read by the end-node search)
-            lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
+            // this node as a source of the next layer, unless that layer reads nothing from
+            // the other lanes (after the last layer the row is read by the end-node search)
+            if (!next_local) lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
             cost_own = best;
         }
-        done = s + 1;
-        if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
-        if (s >= 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer s + 1
-        const bool next_local = s >= 1 && s + 1 < n_s && is_local(c_top, nxt.w_inv);
         if (next_local) {
             // no minimum and no barrier: the abort test of this layer (every cost above the
             // threshold) is kept as a count of the waves for which it holds
