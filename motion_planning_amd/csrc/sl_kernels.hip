@@ -545,6 +545,7 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   point appended) | cntL[n_s] int (pairs per layer) | excL[n_s] int, first_ex[2] int (abort
 //   bookkeeping of layers without a barrier) | offL[n_s] u16 (first pair of the layer)
 //   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
+template <bool SHARED_ROW> // one lateral row for all layers (l_rstride == 0): known at compile time
 __global__ void sl_plan_kernel(SlDev a)
 {
     extern __shared__ double smem[];
@@ -577,7 +578,7 @@ __global__ void sl_plan_kernel(SlDev a)
     }
     const double *s_layers = a.in.s_layers + (size_t)b * n_sm;
     const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
-    const int64_t rstride = a.in.l_rstride;
+    const int64_t rstride = SHARED_ROW ? 0 : a.in.l_rstride;
     const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
     const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
     const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride); // never past the scenario's obstacle slots
@@ -1530,6 +1531,7 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     // 2r/d_s + 1 samples, a few of them twice where two layers share a sample),
     // fewer if LDS would not hold it; layers past its end test their pairs directly
     const int threads = ((n_l + 63) / 64) * 64;
+    const bool shared_row = batch->l_rstride == 0;
     int cap = (7 * batch->ob_stride) / 2;
     if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) cap = atoi(cap_env); // tests: force the overflow path
     else {
@@ -1546,7 +1548,8 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.pair_cap = cap;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
     if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(sl_plan_kernel, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
+    if (shared_row) hipLaunchKernelGGL(sl_plan_kernel<true>, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(sl_plan_kernel<false>, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
     return launch_check("mp_sl_plan");
 }
 
