@@ -545,9 +545,11 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   point appended) | cntL[n_s] int (pairs per layer) | excL[n_s] int, first_ex[2] int (abort
 //   bookkeeping of layers without a barrier) | offL[n_s] u16 (first pair of the layer)
 //   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
-template <bool SHARED_ROW> // one lateral row for all layers (l_rstride == 0): known at compile time
+// SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
+template <bool SHARED_ROW, bool MAPS>
 __global__ void sl_plan_kernel(SlDev a)
 {
+    if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int n_l = a.in.n_l, n_sm = a.in.n_s; // n_sm: layer slots per scenario in every array
@@ -1548,8 +1550,13 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.pair_cap = cap;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
     if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
-    if (shared_row) hipLaunchKernelGGL(sl_plan_kernel<true>, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(sl_plan_kernel<false>, dim3(batch->B), dim3(threads), lds, (hipStream_t)stream, a);
+    const bool maps = cost_map || index_map;
+    const dim3 grid(batch->B), block(threads);
+    hipStream_t st = (hipStream_t)stream;
+    if (shared_row && !maps) hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds, st, a);
+    else if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, true>), grid, block, lds, st, a);
+    else if (!maps) hipLaunchKernelGGL((sl_plan_kernel<false, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((sl_plan_kernel<false, true>), grid, block, lds, st, a);
     return launch_check("mp_sl_plan");
 }
 
