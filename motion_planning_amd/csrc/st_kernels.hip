@@ -297,8 +297,10 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 //   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
 //   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim | hist[N] i32
 //   | cell tables dn[r_tab][N] cst[r_tab][N] | quiet[N] i32
+template <bool TABLES> // the cost / predecessor tables are written to global memory
 __global__ void st_dp_kernel(StDev a)
 {
+    if (!TABLES) a.cost = nullptr, a.pre = nullptr;
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int N = a.n_s_max, n_t = a.n_t, R_max = a.r_max;
@@ -792,7 +794,8 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double) +
                  (size_t)n_s_max * sizeof(int);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(st_dp_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
+    if (cost || pre) hipLaunchKernelGGL(st_dp_kernel<true>, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(st_dp_kernel<false>, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return st_launch_check("mp_st_dp");
 }
 
