@@ -912,9 +912,10 @@ __global__ void sl_plan_kernel(SlDev a)
 // Dynamic LDS (n_sm = layer slots, cap = pair_cap):
 //   layA layQ layP2 layMid [n_sm] | pairs[3][cap] | lc[2][W] double2 | g[2][W] | red[2][16]
 //   | layK[n_sm] int | cntL[n_sm] int | offL[n_sm] u16 | idx8[n_sm*n_l] u8
-template <int W>
+template <int W, bool MAPS>
 __global__ void sl_plan_narrow_kernel(SlDev a)
 {
+    if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
@@ -1521,12 +1522,17 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
         if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: too many layers for LDS"); return MP_E_UNSUPPORTED; }
         const dim3 grid(batch->B), block(threads);
         hipStream_t st = (hipStream_t)stream;
+        const bool nmaps = cost_map || index_map;
+#define SLN_LAUNCH(WW)                                                                              \
+    if (nmaps) hipLaunchKernelGGL((sl_plan_narrow_kernel<WW, true>), grid, block, lds, st, a);      \
+    else hipLaunchKernelGGL((sl_plan_narrow_kernel<WW, false>), grid, block, lds, st, a)
         switch (W) {
-        case 2: hipLaunchKernelGGL(sl_plan_narrow_kernel<2>, grid, block, lds, st, a); break;
-        case 4: hipLaunchKernelGGL(sl_plan_narrow_kernel<4>, grid, block, lds, st, a); break;
-        case 8: hipLaunchKernelGGL(sl_plan_narrow_kernel<8>, grid, block, lds, st, a); break;
-        default: hipLaunchKernelGGL(sl_plan_narrow_kernel<16>, grid, block, lds, st, a); break;
+        case 2: SLN_LAUNCH(2); break;
+        case 4: SLN_LAUNCH(4); break;
+        case 8: SLN_LAUNCH(8); break;
+        default: SLN_LAUNCH(16); break;
         }
+#undef SLN_LAUNCH
         return launch_check("mp_sl_plan");
     }
     // pair store: 3.5 pairs per obstacle slot (an obstacle of radius r meets about
