@@ -207,6 +207,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     const int n1 = n_s - 1;
     // (tb.quiet[] was set to "never" before the barrier in front of this call)
     const double front_step = sh.front[n_s > 1 ? 1 : 0];
+    const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
     for (int q = tid; q < n_s * R; q += nt) {
         const int k = q / n_s, j = q - k * n_s;
         const double s = __dmul_rn((double)j, ds);
@@ -221,7 +222,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
             // estimate only has to be close; the loop makes it safe.
             int dq = n_s;
             if (front_step > 0.0) {
-                const double g = (dnk - s) / front_step;
+                const double g = (dnk - s) * inv_front_step;
                 dq = g < (double)n_s ? (g > 0.0 ? (int)g : 0) : n_s;
             }
             while (dq > 0 && s >= __dsub_rn(dnk, sh.front[dq - 1])) --dq;
