@@ -321,11 +321,18 @@ struct PairStore {
         };
         // every lane of a wave enters `one` the same number of times
         const int tid = threadIdx.x, nt = blockDim.x;
+        // the obstacles of the next round are fetched before this round's are worked on
+        bool act_n = nt + tid < n_ob;
+        double os_n = act_n ? ob_s[nt + tid] : 0.0, ol_n = act_n ? ob_l[nt + tid] : 0.0;
         one(has_ob, my_os, my_ol);
         for (int o0 = nt; o0 < n_ob; o0 += nt) {
-            const int o = o0 + tid;
-            const bool act = o < n_ob;
-            one(act, act ? ob_s[o] : 0.0, act ? ob_l[o] : 0.0);
+            const bool act = act_n;
+            const double os = os_n, ol_ = ol_n;
+            const int o = o0 + nt + tid;
+            act_n = o < n_ob;
+            os_n = act_n ? ob_s[o] : 0.0;
+            ol_n = act_n ? ob_l[o] : 0.0;
+            one(act, os, ol_);
         }
     }
 
