@@ -18,13 +18,16 @@
  *     are written to the `status` array on the device;
  *   - all real numbers are IEEE double, indices are int32.
  *
- * Testing aids read from the environment at launch time (they select between
- * code paths that must give identical results, or tune a launch; unset = the
- * normal choice): MP_SL_NARROW=0 (lattices of up to 16 lanes through the
+ * Testing aids ("knobs": they select between code paths that must give
+ * identical results, or tune a launch; unset = the normal choice).  Each is read
+ * from the environment variable of the same name ONCE, at the library's first
+ * launch that consults it, and can be changed afterwards only through
+ * mp_set_knob(): MP_SL_NARROW=0 (lattices of up to 16 lanes through the
  * thread-per-node kernel), MP_SL_PAIR_CAP=n (size of the kernels' LDS pair
  * store), MP_ST_REGIONS_ONCE=0 (per-layer scans in mp_st_regions),
- * MP_ST_THREADS=n / MP_RL_THREADS=n (workgroup size of mp_st_dp /
- * mp_refline_tables).
+ * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n (workgroup size of
+ * mp_st_dp / mp_refline_tables / the front end of mp_plan_scenes; honoured only
+ * when a multiple of 64 within 64..1024).
  */
 #ifndef MPLATTICE_H
 #define MPLATTICE_H
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 110
+#define MP_VERSION 120
 
 /* host-side return codes */
 #define MP_OK 0
@@ -97,6 +100,10 @@ typedef struct mp_sl_batch {
 
 int mp_version(void);
 const char *mp_last_error(void);
+/* Sets a testing knob by the name of its environment variable; value < 0 = back
+ * to "not set".  MP_E_BADARG for an unknown name or a value the knob does not
+ * accept.  No counterpart in the reference. */
+int mp_set_knob(const char *name, int32_t value);
 
 /* Replaces PathPlanner.find_path (path_planner.py:66-101) with cal_cost/get_path
  * (:104-155) fused in: edge costs are produced and consumed on chip.
@@ -250,8 +257,7 @@ int mp_robot_to_world(int32_t n_pts, const double *x, const double *y, const int
  * plan disjoint blocks of scenarios and exchange one fixed-size record per
  * scenario.  Record of mp_result_record_bytes(n_s, n_t) bytes, little endian:
  *   [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
- *   | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1; lattices of up to 255 lanes)
- *   | zero padding to a multiple of 8
+ *   | st_path i16[n_t] | path_idx i16[n_s] | zero padding to a multiple of 8
  * mp_pack_results writes records [B][record bytes] from the outputs of
  * mp_sl_plan and mp_st_dp (best_cost may be NULL: 0.0). */
 int32_t mp_result_record_bytes(int32_t n_s, int32_t n_t);
@@ -289,7 +295,11 @@ int mp_pack_results(int32_t B, int32_t n_s, int32_t n_t, const int32_t *path_idx
 #define MP_PLAN_E_MAP_TOO_BIG (-4) /* sl_map.py:57-60 ValueError                      */
 #define MP_PLAN_E_BAD_LINE (-5)    /* reference-line tables failed (MP_RL_E_*)        */
 #define MP_PLAN_E_ST_CAPACITY (-6) /* ST grid wider than st_n_s_max, more blocked
-                                      intervals than r_max or path longer than p_max  */
+                                      intervals than r_max, path longer than p_max or
+                                      speed profile longer than q_max                 */
+#define MP_PLAN_E_INDEX (-7)       /* the speed profile or the path points at its arc
+                                      lengths could not be sampled: the reference raises
+                                      IndexError (curve.py:57-65, 82-85)              */
 
 /* Robot-frame scenes (what RobotMap holds after coor_trans, robot_map.py:25-68). */
 typedef struct mp_scene_batch {

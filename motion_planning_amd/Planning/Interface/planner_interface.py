@@ -89,9 +89,11 @@ class PlannerInterface:
         self.status = res["status"].cpu().numpy()
         out = [([], []) for _ in self.scenes]
         wx, wy = res["world_x"].cpu().numpy(), res["world_y"].cpu().numpy()
-        vv, n_prof = res["vv"].cpu().numpy(), res["n_prof"].cpu().numpy()
+        # PIPE_OK guarantees n_final == n_prof > 0: a scene whose result could not be sampled
+        # carries PIPE_INDEX / PIPE_ST_CAPACITY and yields ([], []) like an unplanned one
+        vv, n_final = res["vv"].cpu().numpy(), res["n_final"].cpu().numpy()
         for b in np.flatnonzero(self.status == pipeline.PIPE_OK):
-            n = int(n_prof[b])
+            n = int(n_final[b])
             out[b] = ([Location(float(wx[b, i]), float(wy[b, i])) for i in range(n)], [float(v) for v in vv[b, :n]])
         return out
 

@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
-MP_VERSION = 110   # MP_VERSION of include/mplattice.h this binding was written for
+MP_VERSION = 120   # MP_VERSION of include/mplattice.h this binding was written for
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
 MP_OB_BEHIND, MP_OB_STATIC, MP_OB_STATIC_FAR, MP_OB_DYNAMIC, MP_OB_DYNAMIC_FAR = 0, 1, 2, 3, 4
 MP_PLAN_OK, MP_PLAN_NOT_FOUND, MP_PLAN_E_EMPTY_EDGE, MP_PLAN_E_CAPACITY = 1, 0, -2, -3
-MP_PLAN_E_MAP_TOO_BIG, MP_PLAN_E_BAD_LINE, MP_PLAN_E_ST_CAPACITY = -4, -5, -6
+MP_PLAN_E_MAP_TOO_BIG, MP_PLAN_E_BAD_LINE, MP_PLAN_E_ST_CAPACITY, MP_PLAN_E_INDEX = -4, -5, -6, -7
 MP_F64, MP_I32 = 0, 1
 
 _vp = C.c_void_p
@@ -57,6 +57,7 @@ class PlanParams(C.Structure):       # mp_plan_params
 SIGNATURES = {
     "mp_version": (C.c_int, []),
     "mp_last_error": (C.c_char_p, []),
+    "mp_set_knob": (C.c_int, [C.c_char_p, C.c_int32]),
     "mp_sl_plan": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 7),
     "mp_sl_edge_cost": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams), _vp, _vp, _vp]),
     "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, _vp, C.POINTER(SlParams)] + [_vp] * 7),
@@ -106,6 +107,12 @@ def lib():
 
 class MpError(RuntimeError):
     pass
+
+
+def set_knob(name, value=-1):
+    """Testing aid: select a code path / tune a launch (names in include/mplattice.h);
+    value < 0 puts the knob back to "not set"."""
+    check(lib().mp_set_knob(name.encode(), int(value)), "mp_set_knob")
 
 
 def check(rc, what):

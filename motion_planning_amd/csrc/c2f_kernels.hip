@@ -443,6 +443,10 @@ struct F2cDev {
     const double *inv_x, *inv_s, *inv_y, *inv_theta, *origin;
     const int32_t *n_inv;
     double *x, *y;
+    // whole-replan call only (null otherwise): the scene's outcome and what the two spline
+    // evaluations before this kernel reported
+    int32_t *plan_status;
+    const int32_t *prof_status, *final_status, *n_prof;
 };
 
 // One thread per point (cartesian_frenet_conversion.py:55-60 with get_rxy
@@ -453,6 +457,15 @@ __global__ void f2c_kernel(F2cDev a)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_pts) return;
     const int b = a.pt_scn ? a.pt_scn[p] : p / a.pts_per_scn;
+    if (a.plan_status && p == b * a.pts_per_scn && a.plan_status[b] == MP_PLAN_OK) {
+        // a scene whose profile or final path points were not produced must not read as
+        // planned (PlannerInterface.run_step would raise IndexError from path_sampling,
+        // planner_interface.py:157, curve.py:57-65)
+        const int ps = a.prof_status[b], fs = a.final_status[b];
+        if (ps == MP_RL_E_CAPACITY || fs == MP_RL_E_CAPACITY) a.plan_status[b] = MP_PLAN_E_ST_CAPACITY;
+        else if (ps != MP_RL_OK || fs != MP_RL_OK || a.n_valid[b] != a.n_prof[b] || a.n_prof[b] <= 0)
+            a.plan_status[b] = MP_PLAN_E_INDEX;
+    }
     if (!a.pt_scn && a.n_valid && p - b * a.pts_per_scn >= a.n_valid[b]) {
         a.x[p] = a.y[p] = 0.0;
         return;
@@ -525,7 +538,7 @@ __global__ void curve_eval_kernel(CvDev a)
         int st = MP_RL_OK, m = 0, na = 0;
         double delta = 0.0, t_en = 0.0;
         if (a.mode == 2) {
-            m = a.n_query[b];
+            m = max(a.n_query[b], 0);
             if (m > a.q_max) { st = MP_RL_E_CAPACITY; m = 0; }
         } else {
             t_en = (a.mode == 0) ? t_bios + np_sum_gen(n, [&](int i) { return T[i]; }) : kt[n];
@@ -669,7 +682,7 @@ extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double 
     size_t lds = (size_t)m_max * (sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
     int threads = m_max <= 128 ? 128 : 256;
-    if (const char *t_env = getenv("MP_RL_THREADS")) threads = atoi(t_env); // development aid
+    if (mp_knob_rl_threads() > 0) threads = mp_knob_rl_threads(); // development aid
     hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_refline_tables");
 }
@@ -683,20 +696,25 @@ extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, con
         mp_set_error("null array");
         return MP_E_BADARG;
     }
-    F2cDev a{n_pts, m_max, s, l, pt_scn, 1, nullptr, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv, x, y};
+    F2cDev a{n_pts, m_max, s, l, pt_scn, 1, nullptr, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv, x, y,
+             nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return c2f_launch_check("mp_f2c_batch");
 }
 
 // Frenet->Cartesian of pts_per_scn points per scene (scene-major), of which the
-// first n_valid[b] are converted and the rest set to 0.  Used by mp_plan_scenes.
+// first n_valid[b] are converted and the rest set to 0.  Used by mp_plan_scenes,
+// whose last kernel this is: it also folds the outcome of the two spline
+// evaluations before it (prof_status, final_status, n_prof against n_valid) into
+// the scene's plan_status.
 int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
                 int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
-                const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream)
+                const double *inv_theta, const int32_t *n_inv, double *x, double *y, int32_t *plan_status,
+                const int32_t *prof_status, const int32_t *final_status, const int32_t *n_prof, void *stream)
 {
     const int n_pts = B * pts_per_scn;
     F2cDev a{n_pts, m_max, s, l, nullptr, pts_per_scn, n_valid, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv,
-             x, y};
+             x, y, plan_status, prof_status, final_status, n_prof};
     hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (frenet to cartesian)");
 }

@@ -7,6 +7,15 @@
 #include "../../include/mplattice.h"
 
 #define MP_WAVE 64
+
+// Testing knobs (host side; mp_api.hip): read once from the environment, changed only by
+// mp_set_knob; -1 = not set.  Workgroup-size knobs are whole waves within 64..1024.
+int mp_knob_sl_narrow();
+int mp_knob_sl_pair_cap();
+int mp_knob_st_regions_once();
+int mp_knob_st_threads();
+int mp_knob_rl_threads();
+int mp_knob_fe_threads();
 #define MP_INF (__builtin_huge_val())
 
 // ---- wave-level reductions (64 lanes) ---------------------------------------

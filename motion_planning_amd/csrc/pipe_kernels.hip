@@ -24,7 +24,8 @@
 extern void mp_set_error(const char *fmt, ...);
 int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
                 int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
-                const double *inv_theta, const int32_t *n_inv, double *x, double *y, void *stream);
+                const double *inv_theta, const int32_t *n_inv, double *x, double *y, int32_t *plan_status,
+                const int32_t *prof_status, const int32_t *final_status, const int32_t *n_prof, void *stream);
 int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
                           const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
                           const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
@@ -547,7 +548,7 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
         if (lds > 64 * 1024) { mp_set_error("m_max too large"); return MP_E_UNSUPPORTED; }
         const int n_slot = d.n_st_max + d.n_dy_max * d.n_frames;
         int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);
-        if (const char *t_env = getenv("MP_FE_THREADS")) threads = atoi(t_env); // development aid
+        if (mp_knob_fe_threads() > 0) threads = mp_knob_fe_threads(); // development aid
         hipLaunchKernelGGL(plan_frontend_kernel, dim3(B), dim3(threads), lds, st, f);
         rc = pipe_launch_check("mp_plan_scenes (front end)");
         if (rc) return rc;
@@ -618,5 +619,6 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
                        d.q_max, o.final_s, o.final_l, nullptr, o.n_final, o.final_status, stream);
     if (rc) return rc;
     return mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
-                       o.inv_theta, o.n_inv, o.final_x, o.final_y, stream);
+                       o.inv_theta, o.n_inv, o.final_x, o.final_y, o.status, o.prof_status, o.final_status,
+                       o.n_prof, stream);
 }

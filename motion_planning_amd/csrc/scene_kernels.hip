@@ -47,7 +47,7 @@ __global__ void scene_ingest_kernel(SceneDev a)
     const double r[4] = {a.rot[4 * b], a.rot[4 * b + 1], a.rot[4 * b + 2], a.rot[4 * b + 3]};
     const double tx = a.trans[2 * b], ty = a.trans[2 * b + 1];
     // reference line and ego velocity (robot_map.py:25-44)
-    const int n_way = a.n_way[b];
+    const int n_way = min(max(a.n_way[b], 0), a.way_max);
     for (int i = lane; i < a.way_max; i += MP_WAVE) {
         double x = 0.0, y = 0.0;
         if (i < n_way) {
@@ -64,7 +64,7 @@ __global__ void scene_ingest_kernel(SceneDev a)
         a.ego_vel_r[2 * b + 1] = vy;
     }
     // obstacles (robot_map.py:47-68)
-    const int n_ob = a.n_ob[b];
+    const int n_ob = min(max(a.n_ob[b], 0), a.ob_max); // a damaged count must not reach other scenes' slots
     const size_t ob0 = (size_t)b * a.ob_max;
     int n_st = 0, n_dy = 0; // wave-uniform running counts
     for (int base = 0; base < n_ob; base += MP_WAVE) {
@@ -192,7 +192,7 @@ extern "C" int mp_robot_to_world(int32_t n_pts, const double *x, const double *y
 // Result record of one scenario for the gather across GPUs (nothing in the
 // reference corresponds to it).  Bytes, little endian:
 //   [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
-//   | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1) | zero padding to a multiple of 8
+//   | st_path i16[n_t] | path_idx i16[n_s] | zero padding to a multiple of 8
 // One thread per output byte, so stores are coalesced.
 __global__ void pack_results_kernel(int B, int n_s, int n_t, int width, const int32_t *path_idx,
                                     const int32_t *status, const int32_t *layers_done, const double *best_cost,
@@ -214,8 +214,9 @@ __global__ void pack_results_kernel(int B, int n_s, int n_t, int width, const in
     } else if (o < 12 + 2 * n_t) {
         const int k = (o - 12) >> 1;
         v = (unsigned)st_path[(size_t)b * n_t + k] >> (8 * ((o - 12) & 1));
-    } else if (o < 12 + 2 * n_t + n_s) {
-        v = (unsigned)path_idx[(size_t)b * n_s + (o - 12 - 2 * n_t)];
+    } else if (o < 12 + 2 * n_t + 2 * n_s) {
+        const int k = (o - 12 - 2 * n_t) >> 1;
+        v = (unsigned)path_idx[(size_t)b * n_s + k] >> (8 * ((o - 12 - 2 * n_t) & 1));
     }
     out[g] = (unsigned char)(v & 0xFFu);
 }
@@ -223,7 +224,7 @@ __global__ void pack_results_kernel(int B, int n_s, int n_t, int width, const in
 extern "C" int32_t mp_result_record_bytes(int32_t n_s, int32_t n_t)
 {
     if (n_s <= 0 || n_t <= 0) return -1;
-    return (12 + 2 * n_t + n_s + 7) & ~7;
+    return (12 + 2 * n_t + 2 * n_s + 7) & ~7;
 }
 
 extern "C" int mp_pack_results(int32_t B, int32_t n_s, int32_t n_t, const int32_t *path_idx, const int32_t *status,

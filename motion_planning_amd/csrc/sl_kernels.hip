@@ -862,9 +862,17 @@ __global__ void sl_plan_kernel(SlDev a)
         // layers that ran without a barrier: the first one whose costs all exceeded the
         // threshold is where the reference gives up
         const int s_ex = first_ex[0];
-        if (s_ex != 0x7fffffff && status >= MP_SL_NOT_FOUND) {
-            status = MP_SL_NOT_FOUND;
-            if (a.p.early_exit && s_ex + 1 < done) done = s_ex + 1;
+        if (s_ex != 0x7fffffff) {
+            if (status >= MP_SL_NOT_FOUND) {
+                status = MP_SL_NOT_FOUND;
+                if (a.p.early_exit && s_ex + 1 < done) done = s_ex + 1;
+            } else if (a.p.early_exit && s_ex < done) {
+                // a later layer stopped the loop with an error code (layer `done` was never
+                // relaxed), but the reference had returned "Path not found!" at s_ex before
+                // it ever looked at that layer (path_planner.py:74-77)
+                status = MP_SL_NOT_FOUND;
+                done = s_ex + 1;
+            }
         }
     }
     // rows that were never relaxed keep the reference's initial values
@@ -1514,14 +1522,13 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.pair_cap = 0;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
     // well (the two must agree bit for bit; used by the tests)
-    const char *narrow_env = getenv("MP_SL_NARROW");
-    const bool narrow_ok = !(narrow_env && atoi(narrow_env) == 0);
+    const bool narrow_ok = mp_knob_sl_narrow() != 0;
     if (n_l <= 16 && narrow_ok) {
         const int W = n_l <= 2 ? 2 : (n_l <= 4 ? 4 : (n_l <= 8 ? 8 : 16));
         const int threads = ((n_l * W + 63) / 64) * 64;
         int ncap = (7 * batch->ob_stride) / 2;
         ncap = ncap > SLN_CAP_MAX ? SLN_CAP_MAX : ncap;
-        if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) ncap = atoi(cap_env); // tests: force refills
+        if (mp_knob_sl_pair_cap() >= 0) ncap = mp_knob_sl_pair_cap(); // tests: force refills
         ncap = ncap < 2 ? 2 : (ncap > 2048 ? 2048 : ncap);
         ncap += ncap & 1;
         a.pair_cap = ncap;
@@ -1548,7 +1555,7 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     const int threads = ((n_l + 63) / 64) * 64;
     const bool shared_row = batch->l_rstride == 0;
     int cap = (7 * batch->ob_stride) / 2;
-    if (const char *cap_env = getenv("MP_SL_PAIR_CAP")) cap = atoi(cap_env); // tests: force the overflow path
+    if (mp_knob_sl_pair_cap() >= 0) cap = mp_knob_sl_pair_cap(); // tests: force the overflow path
     else {
         // registers allow 16 waves per CU; a store that lets LDS hold fewer workgroups than
         // that costs more (idle SIMDs) than laying a smaller store out again every few layers

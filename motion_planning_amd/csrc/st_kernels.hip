@@ -786,12 +786,11 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     while (r_tab > 0 && (size_t)r_tab * n_s_max * 16 > 32 * 1024) --r_tab;
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
-    const char *th_env = getenv("MP_ST_THREADS");
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // wide grid gets more lanes per layer
     if (B <= 512 && n_s_max > 64) threads = 512;
-    if (th_env) threads = atoi(th_env);
+    if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
     size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double) +
                  (size_t)n_s_max * sizeof(int);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
@@ -847,8 +846,7 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     // every scan once, results kept in LDS, when they fit (MP_ST_REGIONS_ONCE=0: per-layer scans)
     const int n_items_max = n_st_max + n_dy_max * n_t;
     const size_t lds_once = lds + (size_t)n_items_max * 19 + 16;
-    const char *once_env = getenv("MP_ST_REGIONS_ONCE");
-    if (n_items_max <= 65535 && lds_once <= 64 * 1024 && !(once_env && atoi(once_env) == 0)) {
+    if (n_items_max <= 65535 && lds_once <= 64 * 1024 && mp_knob_st_regions_once() != 0) {
         threads = n_items_max <= 64 ? 64 : (n_items_max <= 128 ? 128 : 256);
         hipLaunchKernelGGL(st_regions_once_kernel, dim3(B), dim3(threads), lds_once, (hipStream_t)stream, a,
                            n_items_max);

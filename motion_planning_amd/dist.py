@@ -8,7 +8,7 @@ runs over gloo on CPU tensors, which is how it is tested without GPUs).
 Record layout (bytes, little endian; the library's mp_pack_results writes the
 same on the device):
   [0,8) best_cost f64 | [8,10) layers_done u16 | [10] status i8 | [11] st_len u8
-  | st_path i16[n_t] | path_idx u8[n_s] (0xFF = -1) | zero padding to a multiple of 8
+  | st_path i16[n_t] | path_idx i16[n_s] | zero padding to a multiple of 8
 """
 import ctypes as C
 
@@ -25,7 +25,7 @@ def shard_range(n_total, rank, world):
 
 def record_width(n_s, n_t):
     """Bytes per scenario record."""
-    return (12 + 2 * n_t + n_s + 7) & ~7
+    return (12 + 2 * n_t + 2 * n_s + 7) & ~7
 
 
 def pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=None):
@@ -39,7 +39,11 @@ def pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=
     if path_idx.is_cuda:
         from . import _lib
         from .batch import _p, _stream
-        args = [t.contiguous() for t in (path_idx, status, layers_done, best_cost, st_path, st_len)]
+        # the kernel reads int32 / float64 through raw pointers
+        args = [t.to(torch.float64 if t is best_cost else torch.int32).contiguous()
+                for t in (path_idx, status, layers_done, best_cost, st_path, st_len)]
+        if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.shape == (B, width)):
+            raise ValueError("pack_results: out must be a contiguous CUDA uint8 tensor [%d, %d]" % (B, width))
         _lib.check(_lib.lib().mp_pack_results(B, n_s, n_t, *[_p(t) for t in args], _p(out), _stream()),
                    "mp_pack_results")
         return out
@@ -49,7 +53,7 @@ def pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=
     out[:, 10] = status.to(torch.int8).view(torch.uint8)
     out[:, 11] = st_len.to(torch.uint8)
     out[:, 12:12 + 2 * n_t] = st_path.to(torch.int16).contiguous().view(torch.uint8).view(B, 2 * n_t)
-    out[:, 12 + 2 * n_t:12 + 2 * n_t + n_s] = (path_idx & 0xFF).to(torch.uint8)
+    out[:, 12 + 2 * n_t:12 + 2 * n_t + 2 * n_s] = path_idx.to(torch.int16).contiguous().view(torch.uint8).view(B, 2 * n_s)
     return out
 
 
@@ -58,8 +62,8 @@ def unpack_results(rec, n_s, n_t):
     best_cost, st_path, st_len)."""
     rec = rec.contiguous()
     B = rec.shape[0]
-    path = rec[:, 12 + 2 * n_t:12 + 2 * n_t + n_s].to(torch.int32)
-    return dict(path_idx=torch.where(path == 255, torch.full_like(path, -1), path),
+    path = rec[:, 12 + 2 * n_t:12 + 2 * n_t + 2 * n_s].contiguous().view(torch.int16).view(B, n_s).to(torch.int32)
+    return dict(path_idx=path,
                 status=rec[:, 10].contiguous().view(torch.int8).to(torch.int32),
                 layers_done=rec[:, 8:10].contiguous().view(torch.int16).view(B).to(torch.int32) & 0xFFFF,
                 best_cost=rec[:, 0:8].contiguous().view(torch.float64).view(B),

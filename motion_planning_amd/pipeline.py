@@ -24,6 +24,7 @@ from ._lib import PlanDims, PlanParams, SceneBatch, check, lib
 PIPE_OK, PIPE_NOT_FOUND = _lib.MP_PLAN_OK, _lib.MP_PLAN_NOT_FOUND
 PIPE_MAP_TOO_BIG, PIPE_BAD_LINE, PIPE_ST_CAPACITY = (_lib.MP_PLAN_E_MAP_TOO_BIG, _lib.MP_PLAN_E_BAD_LINE,
                                                     _lib.MP_PLAN_E_ST_CAPACITY)
+PIPE_INDEX = _lib.MP_PLAN_E_INDEX  # the reference raises IndexError while sampling the result
 N_FRAMES = 11  # dynamic-obstacle frames: t = 0, 0.5, ..., 5.0 (Model/obstacle.py:46-53)
 
 

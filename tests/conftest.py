@@ -19,6 +19,23 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+@pytest.fixture
+def knob():
+    """Sets testing knobs of the library for one test (mp_set_knob; the library reads the
+    environment only once, so tests cannot switch code paths through os.environ) and puts
+    them back to "not set" afterwards."""
+    from motion_planning_amd import _lib
+    used = []
+
+    def set_(name, value):
+        _lib.set_knob(name, value)
+        used.append(name)
+
+    yield set_
+    for name in used:
+        _lib.set_knob(name, -1)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc

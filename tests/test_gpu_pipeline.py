@@ -179,6 +179,36 @@ def test_pipeline_map_too_big_is_a_status():
     assert list(r["status"].cpu().numpy()) == [pl.PIPE_OK, pl.PIPE_MAP_TOO_BIG]
 
 
+def test_unsampled_result_is_not_reported_as_planned():
+    """A scene whose speed profile or final path points could not be produced (here: fewer
+    result slots than the profile needs) must not keep status PIPE_OK with zero-filled path
+    points: the last kernel folds the outcome of both spline evaluations into `status`.
+    With enough slots the same scene plans."""
+    import torch
+    from motion_planning_amd import batch as mb, pipeline as pl
+    sc = dict(rx=-2.0 + 4.5 * np.arange(10), ry=np.zeros(10), ego_vel=np.array([5.0, 0.0]),
+              st_pos=np.zeros((0, 2)), st_rad=np.zeros(0), dy_pos=np.zeros((0, 11, 2)), dy_rad=np.zeros(0))
+    p = pack_scenes([sc, sc])
+    B = 2
+    dev = dict(knots_x=mb.to_dev(p["knots_x"]), knots_y=mb.to_dev(p["knots_y"]),
+               n_knots=mb.to_dev(p["n_knots"], torch.int32), ego_vel=mb.to_dev(p["ego_vel"]),
+               st_pos=mb.to_dev(p["st_pos"]), st_rad=mb.to_dev(p["st_rad"]), n_st=mb.to_dev(p["n_st"], torch.int32),
+               dy_pos=mb.to_dev(p["dy_pos"]), dy_rad=mb.to_dev(p["dy_rad"]), n_dy=mb.to_dev(p["n_dy"], torch.int32),
+               line_vec=torch.zeros(B, dtype=torch.float64, device="cuda"))
+    params = pl.default_params()
+    dims = pl.plan_dims(B, p["knots_x"].shape[1], 1, 1, m_max=232, params=params)
+    a = pl.plan_scenes(dev, dims, params).arrays
+    torch.cuda.synchronize()
+    assert list(a["status"].cpu().numpy()) == [pl.PIPE_OK] * 2
+    n = int(a["n_prof"][0])
+    assert n > 20 and int(a["n_final"][0]) == n
+    dims.q_max = 20   # the profile has n > 20 samples
+    a = pl.plan_scenes(dev, dims, params).arrays
+    torch.cuda.synchronize()
+    assert list(a["status"].cpu().numpy()) == [pl.PIPE_ST_CAPACITY] * 2
+    assert int(a["n_final"][0]) == 0
+
+
 def test_bad_scenes_do_not_disturb_their_neighbours():
     """Scenes with NaN / infinite coordinates, negative or oversized counts and a
     one-knot line share a batch with healthy scenes: the call returns, the healthy

@@ -28,12 +28,13 @@ def gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, split=False,
         assert (st.cpu().numpy() == 1).all()
         out = mb.sl_dp(edge, prm, n_layers=n_layers)
     else:
+        from motion_planning_amd import _lib
         if per_node:
-            os.environ["MP_SL_NARROW"] = "0"
+            _lib.set_knob("MP_SL_NARROW", 0)
         try:
             out = mb.sl_plan(sb, prm)
         finally:
-            os.environ.pop("MP_SL_NARROW", None)
+            _lib.set_knob("MP_SL_NARROW", -1)
     torch.cuda.synchronize()
     res = []
     for b in range(B):
@@ -204,12 +205,12 @@ def test_sl_layer_count_per_scenario(oracle, n_l):
 
 @pytest.mark.parametrize("n_l", [5, 12, 24])
 @pytest.mark.parametrize("cap", [2, 8, 40])
-def test_sl_pair_store_refill(oracle, cap, n_l, monkeypatch):
+def test_sl_pair_store_refill(oracle, cap, n_l, knob):
     """Both fused kernels keep the (sample, obstacle) pairs of all layers in an LDS store
     sized from the obstacle count; when it runs full the remaining layers are laid out
     again, and a layer too big for the whole store tests its pairs directly.  A tiny
     store forces both; results must not change."""
-    monkeypatch.setenv("MP_SL_PAIR_CAP", str(cap))
+    knob("MP_SL_PAIR_CAP", cap)
     rng = np.random.default_rng(5 + cap)
     B, n_s = 6, 14
     s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 2.0, 30, 0.3, 0.9, None, True)
@@ -373,6 +374,46 @@ def test_sl_wall_far_down_the_lattice(oracle, n_l, early_exit):
             assert np.array_equal(res[b][k], res_rows[b][k]), (b, k)
         assert res[b]["status"] == res_rows[b]["status"] and res[b]["layers_done"] == res_rows[b]["layers_done"]
     assert 0 < n_found < B
+
+
+def test_sl_wall_then_short_gap_reports_what_the_reference_reaches_first(oracle):
+    """A wall the reference gives up at (four blocked layers), followed further down by a
+    layer gap shorter than the sample spacing (where the reference would raise, min of an
+    empty array).  With early exit the reference never reaches the short gap, so the
+    scenario is "not found" with the layers up to the wall relaxed; scenarios whose wall
+    stays under the threshold do reach the gap and report the error."""
+    B, n_s, n_l = 4, 30, 64
+    rng = np.random.default_rng(77)
+    s_map, l_map, ego, _, ob_dist = random_batch(rng, B, n_s, n_l, 1.5, 1, 0.45, 0.55, None, False)
+    obs = []
+    for b in range(B):
+        first = 9 + 2 * b
+        n_wall = [4, 2, 5, 3][b]
+        wall_l = np.arange(-1.8, 1.81, 0.3)
+        pts = [(1.5 * (k + 1) - 0.05, l) for k in range(first, first + n_wall) for l in wall_l]
+        obs.append(np.array(pts))
+    s_map = s_map.copy()
+    s_map[:, 24:, :] = s_map[:, 23:24, :] + 0.2 + 1.5 * np.arange(n_s - 24)[None, :, None]   # layer 24 sits 0.2 m behind layer 23
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, shared_row=True)
+    res_rows = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True)
+    kinds = set()
+    for b in range(B):
+        try:
+            ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b])
+        except ValueError:
+            ref = None
+        kinds.add(ref is None)
+        for r in (res[b], res_rows[b]):
+            if ref is None:
+                assert r["status"] == -2, (b, r["status"])        # MP_SL_E_EMPTY_EDGE
+            else:
+                assert not ref["found"] and r["status"] == 0, (b, r["status"])
+                assert r["layers_done"] == ref["layers_done"], b
+                n = ref["layers_done"]
+                assert_costs(r["cost_map"][:n], ref["cost_map"][:n])
+                assert (r["index_map"][n:] == -2).all() and (r["cost_map"][n:] == 0).all()
+    assert kinds == {True, False}
 
 
 def test_sl_largest_fused_lattice(oracle):

@@ -266,13 +266,13 @@ def test_st_regions_pipeline_goldens():
 
 @pytest.mark.parametrize("once", [True, False], ids=["scan_once", "scan_per_layer"])
 @pytest.mark.parametrize("sizes", [(300, 40, 64), (3, 2, 4), (64, 0, 64), (0, 9, 8)], ids=str)
-def test_st_regions_random_vs_oracle(oracle, sizes, once, monkeypatch):
+def test_st_regions_random_vs_oracle(oracle, sizes, once, knob):
     """Both kernels behind mp_st_regions: every (obstacle, layer) scanned once with the
     results kept on chip, and the plain scan per layer used when they do not fit."""
     import torch
     from motion_planning_amd import batch as mb
     if not once:
-        monkeypatch.setenv("MP_ST_REGIONS_ONCE", "0")
+        knob("MP_ST_REGIONS_ONCE", 0)
     rng = np.random.default_rng(77)
     B, n_t, p_max = 12, 11, 150
     n_st_max, n_dy_max, r_max = sizes

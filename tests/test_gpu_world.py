@@ -149,6 +149,48 @@ def test_scene_ingest_random_vs_host_robot_map():
             assert np.array_equal(r["dy_rad"][b, :len(rm.dynamic_ob)], np.array([o.ob_dist for o in rm.dynamic_ob]))
 
 
+def test_scene_ingest_damaged_counts_stay_inside_their_scene():
+    """Obstacle / waypoint counts beyond the arrays (or negative) are clamped to the scene's
+    own slots: the neighbours come out bit for bit as in a clean batch, and the damaged
+    scene reads as one with ob_max obstacles (or none)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(15)
+    B, O, W = 5, 70, 9
+    n_ob = np.array([70, 12, 30, 0, 70], np.int32)
+    n_way = np.full(B, W, np.int32)
+    rot = np.broadcast_to(np.eye(2), (B, 2, 2)).copy()
+    trans = rng.uniform(-50, 50, (B, 2))
+    ego_vel = rng.uniform(-8, 8, (B, 2))
+    way = trans[:, None, :] + rng.uniform(-5, 40, (B, W, 2))
+    ob_pos = trans[:, None, :] + rng.uniform(-15, 15, (B, O, 2))
+    ob_vel = rng.uniform(-4, 4, (B, O, 2))
+    ob_vel[rng.random((B, O)) < 0.5] = 0.0
+    ob_rad = rng.uniform(0.4, 1.2, (B, O))
+    clean = mb.scene_ingest(rot, trans, ego_vel, way, n_way, ob_pos, ob_vel, ob_rad, n_ob)
+    torch.cuda.synchronize()
+    clean = {k: v.cpu().numpy().copy() for k, v in clean.items()}
+    bad_ob, bad_way = n_ob.copy(), n_way.copy()
+    bad_ob[1], bad_ob[2], bad_ob[4] = 100000, -7, 71     # scene 4 is the last one: past the buffers' end
+    bad_way[3] = 1000
+    full = n_ob.copy()
+    full[1], full[2] = O, 0
+    want = mb.scene_ingest(rot, trans, ego_vel, way, n_way, ob_pos, ob_vel, ob_rad, full)
+    torch.cuda.synchronize()
+    want = {k: v.cpu().numpy().copy() for k, v in want.items()}
+    r = mb.scene_ingest(rot, trans, ego_vel, way, bad_way, ob_pos, ob_vel, ob_rad, bad_ob)
+    torch.cuda.synchronize()
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    assert np.array_equal(r["n_st"], want["n_st"]) and np.array_equal(r["n_dy"], want["n_dy"])
+    for b in range(B):
+        ns, nd = int(want["n_st"][b]), int(want["n_dy"][b])
+        assert np.array_equal(r["st_pos"][b, :ns], want["st_pos"][b, :ns]), b
+        assert np.array_equal(r["dy_pos"][b, :nd], want["dy_pos"][b, :nd]), b
+        assert np.array_equal(r["knots_x"][b], clean["knots_x"][b]) and np.array_equal(r["knots_y"][b], clean["knots_y"][b])
+    for b in (0, 3, 4):
+        assert np.array_equal(r["ob_class"][b, :n_ob[b]], clean["ob_class"][b, :n_ob[b]]), b
+
+
 def test_robot_to_world_inverts_ingest():
     import torch
     from motion_planning_amd import batch as mb
@@ -177,7 +219,8 @@ def test_pack_results_device_matches_host():
     from motion_planning_amd import dist as mdist
     rng = np.random.default_rng(8)
     B, n_s, n_t = 300, 13, 11
-    path = torch.as_tensor(rng.integers(-1, 255, (B, n_s)).astype(np.int32))
+    path = torch.as_tensor(rng.integers(-1, 256, (B, n_s)).astype(np.int32))
+    path[0, :3] = torch.tensor([255, -1, 0], dtype=torch.int32)   # lane 255 of a 256-lane lattice is not "-1"
     status = torch.as_tensor(rng.integers(-4, 2, B).astype(np.int32))
     layers = torch.as_tensor(rng.integers(0, 600, B).astype(np.int32))
     best = torch.as_tensor(np.where(rng.random(B) < 0.2, np.nan, rng.uniform(0, 1e9, B)))
