@@ -364,6 +364,29 @@ int64_t mp_plan_arena_bytes(const mp_plan_dims *dims);
 int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                    void *arena, int64_t arena_bytes, void *stream);
 
+/* ---- whole replan without a caller-owned arena ------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): mp_plan_scenes with every intermediate array in a fixed
+ * device array of MP_PLAN_STATIC_BYTES that belongs to the library (each GPU the
+ * library runs on holds one until the process ends).  The caller passes the
+ * scenes and the result arrays only; nothing is allocated or freed, by the
+ * library or on its behalf.  Sizes whose arena (mp_plan_arena_bytes) exceeds
+ * MP_PLAN_STATIC_BYTES, and want_maps, are refused with MP_E_UNSUPPORTED.  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * streams, two threads) race; calls on one stream are safe back to back.
+ *   status   [B]         MP_PLAN_*
+ *   n_points [B]         valid entries of x / y / speed (0 unless MP_PLAN_OK)
+ *   x, y     [B][q_max]  path points in the robot frame (0 beyond n_points)
+ *   speed    [B][q_max]  speed profile at those points, m/s */
+#define MP_PLAN_STATIC_BYTES (32u << 20)
+typedef struct mp_plan_result {
+    int32_t *status, *n_points;
+    double *x, *y, *speed;
+} mp_plan_result;
+int mp_plan_scenes_static(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                          const mp_plan_result *result, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,13 @@ class PlanDims(C.Structure):         # mp_plan_dims
                                          "n_s_max", "p_max", "n_t", "st_n_s_max", "r_max", "q_max", "want_maps")]
 
 
+class PlanResult(C.Structure):       # mp_plan_result
+    _fields_ = [(n, _vp) for n in ("status", "n_points", "x", "y", "speed")]
+
+
+MP_PLAN_STATIC_BYTES = 32 << 20
+
+
 class PlanParams(C.Structure):       # mp_plan_params
     _fields_ = [("l_width", C.c_double), ("save_width", C.c_double), ("layer_gap", C.c_double),
                 ("max_map_len", C.c_double), ("d_x", C.c_double), ("path_dt", C.c_double), ("sl", SlParams),
@@ -81,6 +88,8 @@ SIGNATURES = {
     "mp_plan_array_info": (C.c_int, [C.POINTER(PlanDims), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mp_plan_arena_bytes": (C.c_int64, [C.POINTER(PlanDims)]),
+    "mp_plan_scenes_static": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams),
+                                        C.POINTER(PlanResult), _vp]),
     "mp_plan_scenes": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp, C.c_int64,
                                  _vp]),
 }

@@ -21,6 +21,8 @@
 
 #include <string.h>
 
+#include <mutex>
+
 extern void mp_set_error(const char *fmt, ...);
 int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
                 int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
@@ -476,8 +478,17 @@ static int pipe_launch_check(const char *what)
     return MP_OK;
 }
 
+static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out);
+
 extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                               void *arena, int64_t arena_bytes, void *stream)
+{
+    return plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr);
+}
+
+static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out)
 {
     int rc = check_dims(dims);
     if (rc) return rc;
@@ -513,6 +524,7 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
         PLAN_ARRAYS(X)
 #undef X
     }
+    if (ptrs_out) *ptrs_out = o;
     hipStream_t st = (hipStream_t)stream;
     const mp_plan_params &p = *params;
     const int B = d.B;
@@ -621,4 +633,98 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
     return mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
                        o.inv_theta, o.n_inv, o.final_x, o.final_y, o.status, o.prof_status, o.final_status,
                        o.n_prof, stream);
+}
+
+// ---------------------------------------------------------------------------
+// The whole replan for callers that cannot allocate device memory.
+// mp_plan_scenes_static is mp_plan_scenes with the arena (every intermediate
+// array of the chain) in a fixed device array that is part of the library's code
+// object; the caller passes only the scenes and the result arrays.  One array per
+// GPU, shared by every call on that GPU and keeping the previous call's contents:
+// the chain clears what it needs cleared (the same memset as mp_plan_scenes), and
+// two calls that overlap on one GPU (two streams, two threads) race.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[MP_PLAN_STATIC_BYTES];
+
+#define PLAN_STATIC_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[PLAN_STATIC_MAX_DEVICES]; // device address of `scratch` on each GPU, looked up once
+
+// Device address of the current GPU's copy of `scratch` (the array's name is only a
+// host-side handle; every GPU holds its own copy at its own address).
+static int plan_static_arena(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= PLAN_STATIC_MAX_DEVICES) {
+        mp_set_error("mp_plan_scenes_static: no usable current device (%s)",
+                     e != hipSuccess ? hipGetErrorString(e) : "device index out of range");
+        return MP_E_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            mp_set_error("mp_plan_scenes_static: hipGetSymbolAddress failed (%s)", hipGetErrorString(e));
+            return MP_E_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MP_OK;
+}
+
+struct PlanOutDev {
+    int32_t B, q_max;
+    const int32_t *status, *n_final;
+    const double *final_x, *final_y, *vv;
+    mp_plan_result out;
+};
+
+// Results out of the arena into the caller's arrays, one thread per profile slot.
+__global__ void plan_copy_out_kernel(PlanOutDev a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.q_max) return;
+    a.out.x[i] = a.final_x[i];
+    a.out.y[i] = a.final_y[i];
+    a.out.speed[i] = a.vv[i];
+    if (i < a.B) {
+        const int st = a.status[i];
+        a.out.status[i] = st;
+        a.out.n_points[i] = st == MP_PLAN_OK ? a.n_final[i] : 0;
+    }
+}
+
+extern "C" int mp_plan_scenes_static(const mp_scene_batch *scenes, const mp_plan_dims *dims,
+                                     const mp_plan_params *params, const mp_plan_result *result, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!result || !result->status || !result->n_points || !result->x || !result->y || !result->speed) {
+        mp_set_error("mp_plan_scenes_static: null result array");
+        return MP_E_BADARG;
+    }
+    if (dims->want_maps) {
+        mp_set_error("mp_plan_scenes_static: want_maps is not available (the tables stay in the library's scratch)");
+        return MP_E_UNSUPPORTED;
+    }
+    const int64_t need = mp_plan_arena_bytes(dims);
+    if (need < 0 || need > (int64_t)MP_PLAN_STATIC_BYTES) {
+        mp_set_error("mp_plan_scenes_static: these sizes need %lld bytes of scratch, the library holds %lld; "
+                     "plan fewer scenes per call or use mp_plan_scenes with a caller-owned arena",
+                     (long long)need, (long long)MP_PLAN_STATIC_BYTES);
+        return MP_E_UNSUPPORTED;
+    }
+    void *arena = nullptr;
+    rc = plan_static_arena(&arena);
+    if (rc) return rc;
+    PlanPtrs o;
+    rc = plan_scenes_impl(scenes, dims, params, arena, (int64_t)MP_PLAN_STATIC_BYTES, stream, &o);
+    if (rc) return rc;
+    PlanOutDev c{dims->B, dims->q_max, o.status, o.n_final, o.final_x, o.final_y, o.vv, *result};
+    const int n = dims->B * dims->q_max;
+    hipLaunchKernelGGL(plan_copy_out_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, c);
+    return pipe_launch_check("mp_plan_scenes_static (results)");
 }

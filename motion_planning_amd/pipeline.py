@@ -118,6 +118,32 @@ def plan_scenes(scenes, dims, params, arena=None):
     return arena
 
 
+def plan_scenes_static(scenes, dims, params, out=None):
+    """Enqueues one mp_plan_scenes_static call: the same chain with every intermediate
+    array in the library's own fixed device array, for callers that must not allocate
+    (the tensors in `out` -- status, n_points [B] int32; x, y, speed [B, q_max] float64 --
+    are the caller's; they are created here only when not passed in).  Raises MpError
+    when the sizes need more scratch than the library holds."""
+    B, q = dims.B, dims.q_max
+    if out is None:
+        dev = mb._dev()
+        out = dict(status=torch.empty(B, dtype=torch.int32, device=dev),
+                   n_points=torch.empty(B, dtype=torch.int32, device=dev),
+                   x=torch.empty((B, q), dtype=torch.float64, device=dev),
+                   y=torch.empty((B, q), dtype=torch.float64, device=dev),
+                   speed=torch.empty((B, q), dtype=torch.float64, device=dev))
+    for k, shp, dt in (("status", (B,), torch.int32), ("n_points", (B,), torch.int32), ("x", (B, q), torch.float64),
+                       ("y", (B, q), torch.float64), ("speed", (B, q), torch.float64)):
+        t = out[k]
+        if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("plan_scenes_static: out[%r] must be a contiguous CUDA %s tensor of shape %s" % (k, dt, shp))
+    sb = SceneBatch(*[mb._p(scenes.get(n)) for n, _ in SceneBatch._fields_])
+    res = _lib.PlanResult(*[mb._p(out[k]) for k, _ in _lib.PlanResult._fields_])
+    check(lib().mp_plan_scenes_static(C.byref(sb), C.byref(dims), C.byref(params), C.byref(res), mb._stream()),
+          "mp_plan_scenes_static")
+    return out
+
+
 def plan_batch(knots_x, knots_y, n_knots, ego_vel, st_pos, st_rad, n_st, dy_pos, dy_rad, n_dy,
                line_vec=None, l_width=3.5, save_width=0.6, n_l=5, speed_lim=25.0 * 5.0 / 18.0, plan_time=5,
                want_maps=False, path_planner="dp", m_max=None, arena=None):
