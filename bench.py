@@ -7,15 +7,27 @@ obstacles per scenario (every layer relaxed, no early abort) followed by the
 ST speed DP on a default ST lattice (11 time layers x 97 s cells, 5 moving
 blocked intervals per layer), and -- with more than one GPU -- one RCCL
 all-gather of the per-scenario results.  Scenarios are independent, so ranks
-take disjoint blocks of scenarios (weak scaling: 4096 per GPU).
+take disjoint contiguous blocks of scenarios and nothing else is exchanged.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-prints ONE JSON line (rank 0).  For N > 1 launch with torch.distributed.run.
+  N = 1: 4096 scenarios on one GPU.
+  N > 1: 65536 scenarios split over the N GPUs (strong scaling); --scenarios P
+         instead gives every GPU P scenarios (weak scaling).
+With N > 1 and no launcher in the environment the script starts its own N ranks
+(torch.distributed.run) before it touches the GPU.
+
+Prints ONE JSON line (rank 0): plans/sec of the timed steps (median of --reps
+timed blocks of K steps each), the per-kernel rooflines, the same workload with
+the host->device copies of its inputs inside the step, the CPU oracle timed on a
+sample of the same batch (and its results compared with the GPU's), and a short
+run of the whole-replan workload (--workload pipeline makes that the headline).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,8 +41,10 @@ N_S, N_L, N_OB = 64, 128, 50
 ST_N_T, ST_N_S, ST_R = 11, 97, 5
 SPEED_LIM = 25.0 * 5.0 / 18.0
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
-VALU_FP32_PEAK_TF = 157.3    # MI355X vector fp32 spec
-VALU_FP64_PEAK_TF = 78.6     # MI355X vector fp64 spec
+VALU_FP64_PEAK_TF = 78.6     # MI355X vector fp64 spec (counts a fused multiply-add as two)
+VALU_FP64_NO_FMA_TF = 39.3   # the same pipes when no multiply-add may be fused (bit-exact Python arithmetic)
+ISSUE_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9   # wave64 vector instructions/s: 1024 SIMDs, 4 cycles each, 2.4 GHz
+CFG4_TOTAL = 65536
 
 
 def make_scenarios(first_id, B):
@@ -92,9 +106,13 @@ def make_scenes(B, n_st=192, n_dy=64, seed=5):
                 dy_rad=np.full((B, n_dy), 0.8), n_dy=np.full(B, n_dy, np.int32))
 
 
+# ---------------------------------------------------------------------------
+# CPU legs (the oracle is the checker and the reported baseline, never the product)
+# ---------------------------------------------------------------------------
 def cpu_pipeline(sc, n_sample, threads):
     """The CPU oracle's whole replan (Frenet map, SL DP, path sampling, ST map, ST DP,
-    speed profile, conversion back) on the first n_sample scenes, `threads` at a time."""
+    speed profile, conversion back) on the first n_sample scenes, `threads` at a time.
+    Returns (plans/s, seconds, per-scene outcome: None = no plan, else the final path)."""
     import contextlib
     import io
     from concurrent.futures import ThreadPoolExecutor
@@ -109,25 +127,82 @@ def cpu_pipeline(sc, n_sample, threads):
         try:
             sl = orc.SLMap(sc["knots_x"][b, :nk], sc["knots_y"][b, :nk], 0.0, sc["ego_vel"][b], st, dy)
         except ValueError:
-            return 0
+            return None
         found, curve, _ = orc.sl_plan(sl)
         if not found:
-            return 0
+            return None
         pb = sl.path_sampling(curve)
         n_s, n_t = orc.st_dims(pb[-1][0])
         down, up, n_reg = orc.st_add_obstacle(n_t, pb, sl.st_ob_traj, sl.dy_ob_traj)
         sr = orc.st_find_speed(n_t, n_s, down, up, n_reg, sl.robot_vel, SPEED_LIM)
         ss, vv = orc.speed_profile(sr["path_s_ind"], sl.robot_vel)
-        sl.path_convert(sl.path_sampling(curve, ss))
-        return 1
+        xy = sl.path_convert(sl.path_sampling(curve, ss))
+        return np.asarray(xy, dtype=np.float64), np.asarray(vv, dtype=np.float64)
 
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()), ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, range(n_sample)))
+        res = list(ex.map(one, range(n_sample)))
     dt = time.perf_counter() - t0
-    return n_sample / dt, dt
+    return n_sample / dt, dt, res
 
 
+def cpu_baseline(sc, n_sample, threads):
+    """The CPU oracle (a quirk-exact C restatement of the reference planner) on the
+    first n_sample scenarios of the same batch, `threads` scenarios at a time.
+    Returns (plans/s, seconds, [(SL result, ST result), ...])."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+
+    def one(b):
+        s_map = np.repeat(sc["s_layers"][b][:, None], N_L, axis=1)
+        l_map = np.broadcast_to(sc["l_row"][b], (N_S, N_L))
+        ob = np.stack([sc["ob_s"][b], sc["ob_l"][b]], 1)
+        r = orc.sl_find_path(s_map, l_map, int((N_L - 1) / 2), sc["ego"][b], ob, sc["ob_dist"][b],
+                             no_early_exit=True)
+        s = orc.st_find_speed(ST_N_T, ST_N_S, sc["down"][b], sc["up"][b], sc["n_reg"][b], float(sc["cur_vel"][b]),
+                              SPEED_LIM)
+        best = float(r["cost_map"][-1, r["path_idx"][-1]]) if r["found"] else float("nan")
+        return (dict(found=bool(r["found"]), path_idx=r["path_idx"].copy(), layers_done=int(r["layers_done"]),
+                     best_cost=best), s["path_s_ind"].copy())
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(one, range(n_sample)))
+    dt = time.perf_counter() - t0
+    return n_sample / dt, dt, res
+
+
+def check_lattice_parity(cpu_res, out, st):
+    """GPU outputs of the timed run against the oracle's, scenario by scenario: outcome,
+    lane per layer, layers relaxed and end cost of the SL plan; the ST plan's s indices.
+    A lane sequence may differ only where the two end costs tie within 1e-9 relative."""
+    n = len(cpu_res)
+    status = out.status[:n].cpu().numpy()
+    path = out.path_idx[:n].cpu().numpy()
+    layers = out.layers_done[:n].cpu().numpy()
+    best = out.best_cost[:n].cpu().numpy()
+    st_path = st["path_s_ind"][:n].cpu().numpy()
+    st_len = st["path_len"][:n].cpu().numpy()
+    ties = 0
+    for b, (r, sp) in enumerate(cpu_res):
+        assert (status[b] == 1) == r["found"], "scenario %d: found differs from the oracle" % b
+        assert int(layers[b]) == r["layers_done"], "scenario %d: layers relaxed differ" % b
+        if r["found"]:
+            assert abs(best[b] - r["best_cost"]) <= 1e-9 * abs(r["best_cost"]), "scenario %d: end cost differs" % b
+            if not np.array_equal(path[b], r["path_idx"]):
+                ties += 1   # same end cost within 1e-9: a tie between two lane sequences
+        else:
+            assert (path[b] == -1).all() and np.isnan(best[b])
+        assert int(st_len[b]) == len(sp) and np.array_equal(st_path[b, :len(sp)], sp), \
+            "scenario %d: ST path differs from the oracle" % b
+    return ties
+
+
+# ---------------------------------------------------------------------------
+# launch plumbing
+# ---------------------------------------------------------------------------
 def exchange_on(world):
     """The result exchange runs with more than one rank; MP_BENCH_FORCE_DIST=1 also runs it
     (process group, barrier, all-gather, max over ranks) in a one-rank job, which is how the
@@ -135,25 +210,46 @@ def exchange_on(world):
     return world > 1 or os.environ.get("MP_BENCH_FORCE_DIST") == "1"
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves, before this process has
+    touched a GPU (counting devices does not initialise one), and hand on their exit code."""
+    import torch
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if args.launch_check:
+        env["MP_BENCH_BACKEND"] = "gloo"
+    elif n_dev < args.gpus and "MP_BENCH_BACKEND" not in env:
+        sys.stderr.write("bench.py: %d GPU(s) visible for --gpus %d: ranks share the card(s) and the gather runs "
+                         "over gloo (a rehearsal, not a scaling measurement)\n" % (n_dev, args.gpus))
+        env["MP_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 class ResultGather:
     """The per-step exchange of result records when more than one GPU takes part: pack on
     the device (one kernel), then one all-gather issued asynchronously on the process
     group's own stream into one of two buffer pairs, so that the exchange of batch k runs
     while the kernels of batch k+1 do; a buffer pair is waited for before it is reused,
-    and drain() waits for everything (called before the clock stops)."""
+    and drain() waits for everything (called before the clock stops).  Shards are padded
+    to the largest one (rows), so ranks may hold different numbers of scenarios."""
 
-    def __init__(self, world, backend, B, n_s, n_t):
+    def __init__(self, world, backend, B, rows, n_s, n_t, device="cuda"):
         import torch
         from motion_planning_amd import dist as mdist
-        self.world, self.backend, self.mdist = world, backend, mdist
+        self.world, self.backend, self.mdist, self.B, self.rows = world, backend, mdist, B, rows
         self.k = 0
         self.active = exchange_on(world)
         if not self.active:
             return
         width = mdist.record_width(n_s, n_t)
         gdev = "cuda" if backend == "nccl" else "cpu"
-        self.packed = [torch.empty((B, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
-        self.gathered = [torch.empty((world * B, width), dtype=torch.uint8, device=gdev) for _ in range(2)]
+        self.packed = [torch.zeros((rows, width), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((world * rows, width), dtype=torch.uint8, device=gdev) for _ in range(2)]
         self.pending = [None, None]
 
     def submit(self, path_idx, status, layers_done, best_cost, st_path, st_len):
@@ -162,7 +258,7 @@ class ResultGather:
         i = self.k & 1
         if self.pending[i] is not None:
             self.pending[i].wait()
-        self.mdist.pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=self.packed[i])
+        self.mdist.pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=self.packed[i][:self.B])
         src = self.packed[i] if self.backend == "nccl" else self.packed[i].cpu()
         self.pending[i] = self.mdist.gather_results_same_size(src, self.gathered[i], async_op=True)
         self.k += 1
@@ -178,15 +274,165 @@ class ResultGather:
     def last(self):
         return self.gathered[(self.k - 1) & 1]
 
+    def rows_of(self, rank, count):
+        """Rank `rank`'s records of the last exchange (its first `count` rows)."""
+        return self.last()[rank * self.rows:rank * self.rows + count]
 
-def bench_pipeline(args, world, rank, backend):
-    """--workload pipeline: one step = one mp_plan_scenes call over B scenes resident in
-    HBM (every stage of the replan) and, with more than one GPU, the result gather."""
+
+class Job:
+    """Rank, world, backend and the shard of this process."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # MP_BENCH_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks
+        # share the card and the gather is staged through host memory)
+        self.backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
+        self.gpu = not args.launch_check
+        if self.gpu:
+            torch.cuda.set_device(local % torch.cuda.device_count())
+        self.dist_on = exchange_on(self.world)
+        if self.dist_on:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)   # a forced one-rank job started without a launcher
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            else:
+                dist.init_process_group(self.backend)
+        # workload size: per-GPU count (weak) or a total split over the ranks (strong)
+        from motion_planning_amd import dist as mdist
+        if args.total_scenarios is None and args.scenarios is None:
+            if self.world > 1:
+                args.total_scenarios = CFG4_TOTAL
+            else:
+                args.scenarios = 4096
+        if args.total_scenarios is not None:
+            self.scaling = "strong"
+            self.total = args.total_scenarios
+            self.lo, self.hi = mdist.shard_range(self.total, self.rank, self.world)
+            self.rows = mdist.shard_range(self.total, 0, self.world)[1]   # rank 0 holds a largest shard
+        else:
+            self.scaling = "weak"
+            self.total = args.scenarios * self.world
+            self.lo, self.hi = self.rank * args.scenarios, (self.rank + 1) * args.scenarios
+            self.rows = args.scenarios
+        self.B = self.hi - self.lo
+        if self.B <= 0:
+            raise SystemExit("rank %d has no scenarios (total %d over %d ranks)" % (self.rank, self.total, self.world))
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+        if self.gpu:
+            torch.cuda.synchronize()
+        if self.dist_on:
+            dist.barrier()
+        if self.gpu:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+        if not self.dist_on:
+            return seconds
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor(seconds, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def close(self):
+        import torch.distributed as dist
+        if self.dist_on:
+            dist.destroy_process_group()
+
+
+def timed_blocks(job, step, drain, steps, reps):
+    """`reps` timed blocks of exactly `steps` steps, each bracketed by barrier + device
+    synchronisation on both sides; returns the blocks' seconds (max over ranks)."""
+    secs = []
+    for _ in range(reps):
+        job.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        drain()
+        job.fence()
+        secs.append(time.perf_counter() - t0)
+    return job.max_over_ranks(secs)
+
+
+def load_pmc(name="pmc_latest.json"):
+    """Per-kernel counter means (per launch) from the last committed rocprofv3 --pmc passes of this
+    same command; bench.py cannot collect them itself."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        k = dict(d.get("kernels", {}))
+        k["_source"] = d.get("source")
+        k["_scenarios"] = d.get("scenarios", 4096)
+        return k
+    except (OSError, ValueError):
+        return {}
+
+
+def launch_check(job):
+    """--launch-check: the launcher, the sharding and the result exchange without any
+    kernel (CPU tensors, gloo), so that the multi-rank plumbing of this script can be
+    exercised where no GPU is visible.  Every rank builds the records its scenarios would
+    produce from their ids, exchanges them twice through ResultGather and checks that it
+    holds every scenario's record in scenario order."""
     import torch
-    import torch.distributed as dist
+    from motion_planning_amd import dist as mdist
+    n_s, n_t = 6, ST_N_T
+
+    def fake(lo, hi):
+        ids = torch.arange(lo, hi, dtype=torch.int32)
+        path = (ids[:, None] * 7 + torch.arange(n_s, dtype=torch.int32)[None]) % 128
+        status = (ids % 3 != 0).to(torch.int32)
+        layers = torch.full_like(ids, n_s)
+        best = ids.double() * 1.25 + 0.1
+        st_len = (ids % n_t + 1).to(torch.int32)
+        st_path = ((ids[:, None] + torch.arange(n_t, dtype=torch.int32)[None]) % 97).to(torch.int32)
+        return path, status, layers, best, st_path, st_len
+
+    gather = ResultGather(job.world, job.backend, job.B, job.rows, n_s, n_t, device="cpu")
+    mine = fake(job.lo, job.hi)
+    shards = []
+    for _ in range(2):
+        gather.submit(*mine)
+    gather.drain()
+    job.fence()
+    for r in range(job.world):
+        lo, hi = (mdist.shard_range(job.total, r, job.world) if job.scaling == "strong"
+                  else (r * job.B, (r + 1) * job.B))
+        shards.append(hi - lo)
+        if gather.active:
+            u = mdist.unpack_results(gather.rows_of(r, hi - lo), n_s, n_t)
+            want = fake(lo, hi)
+            assert torch.equal(u["path_idx"], want[0]) and torch.equal(u["status"], want[1])
+            assert torch.equal(u["best_cost"], want[3]) and torch.equal(u["st_path"], want[4])
+    if job.rank == 0:
+        print(json.dumps({"launch_check": "ok", "n_gpus": job.world, "total_scenarios": job.total,
+                          "scaling": job.scaling, "shards": shards, "backend": job.backend if job.dist_on else None}))
+
+
+# ---------------------------------------------------------------------------
+# whole-replan workload
+# ---------------------------------------------------------------------------
+def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
+    """One step = one mp_plan_scenes call over B scenes resident in HBM (every stage of the
+    replan) and, with more than one GPU, the result gather.  Returns the result dict."""
+    import torch
     from motion_planning_amd import batch as mb, dist as mdist, pipeline as pl
 
-    B = args.scenarios
+    B = args.pipeline_scenes
+    world, rank = job.world, job.rank
     sc = make_scenes(B, seed=5 + rank)
     dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
     dev["line_vec"] = torch.zeros(B, dtype=torch.float64, device="cuda")
@@ -195,121 +441,125 @@ def bench_pipeline(args, world, rank, backend):
                         params=params)
     arena = pl.PlanArena(dims)
     a = arena.arrays
-    gather = ResultGather(world, backend, B, dims.n_s_max, dims.n_t)
+    gather = ResultGather(world, job.backend, B, B, dims.n_s_max, dims.n_t)
 
-    def step():
+    def step(_i=None):
         pl.plan_scenes(dev, dims, params, arena)
         gather.submit(a["path_idx"], a["sl_status"], a["layers_done"], a["best_cost"], a["st_path_s_ind"],
                       a["st_path_len"])
 
-    def fence():
-        torch.cuda.synchronize()
-        if exchange_on(world):
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     gather.drain()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    gather.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if exchange_on(world):
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        u = mdist.unpack_results(gather.last()[rank * B:(rank + 1) * B].to("cuda"), dims.n_s_max, dims.n_t)
+    secs = timed_blocks(job, step, gather.drain, steps, reps)
+    if job.dist_on:
+        u = mdist.unpack_results(gather.rows_of(rank, B).to("cuda"), dims.n_s_max, dims.n_t)
         assert torch.equal(u["path_idx"], a["path_idx"]) and torch.equal(u["st_path"], a["st_path_s_ind"])
     status = a["status"].cpu().numpy()
     assert set(np.unique(status)) <= {1, 0, -4}, "unexpected scene status %s" % np.unique(status)
-    n_prof = a["n_prof"].cpu().numpy()
-    assert (n_prof[status == 1] >= 2).all()
+    n_final = a["n_final"].cpu().numpy()
+    assert (n_final[status == 1] >= 2).all()
+    # per-stage durations from HIP events between the stages (three calls, averaged)
+    stage = None
+    for _ in range(3):
+        _, ms = pl.plan_scenes_timed(dev, dims, params, arena)
+        stage = ms if stage is None else [(n, t0 + t1) for (n, t0), (_, t1) in zip(stage, ms)]
+    stage = [(n, t / 3.0) for n, t in stage]
     if rank != 0:
-        return
+        return None
+    sec = float(np.median(secs))
+    ms = 1e3 * sec / steps
+    stage_ms = dict(stage)
+    # algorithmic work of the three dominant stages, as the reference writes it
+    n_t = dims.n_t
+    st_n_s = a["st_n_s"].cpu().numpy().astype(np.float64)
+    n_reg = a["st_n_reg"].cpu().numpy().astype(np.float64)          # [B, n_t]
+    ok = status == 1
+    per_layer_edges = st_n_s * (st_n_s + 1) / 2.0                    # layers 2..n_t-1
+    flop_st = float(np.sum(ok * (st_n_s * (30 + 9 * n_reg[:, 1]) +
+                                 np.sum(per_layer_edges[:, None] * (30 + 9 * n_reg[:, 2:]), axis=1))))
+    M = a["tab_m"].cpu().numpy().astype(np.float64)
+    pts = sc["n_st"] + 11.0 * sc["n_dy"] + 1
+    flop_fe = float(np.sum((status != -5) * pts * (7 * M + 40)))
+    pmc = load_pmc("pmc_pipeline_latest.json")
+
+    def stage_roof(name, kernel, flop, note):
+        t = stage_ms[name] * 1e-3
+        r = {"kernel": kernel, "stage": name, "kernel_ms": stage_ms[name], "bound": "valu",
+             "achieved": flop / t / 1e12, "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s",
+             "frac": flop / t / 1e12 / VALU_FP64_PEAK_TF, "algorithmic_flop_per_launch": flop, "note": note}
+        k = pmc.get(kernel, {})
+        if "SQ_INSTS_VALU" in k and pmc.get("_scenarios") == B:
+            r["issue_slots_used"] = k["SQ_INSTS_VALU"] / t / 1e9 / ISSUE_PEAK_GINST
+        return r
+
+    roofs = [
+        stage_roof("ST speed DP", "st_dp_kernel", flop_st,
+                   "(30 + 9 R) flop per ST edge over the scenes that reach the speed search, R = that layer's "
+                   "interval count"),
+        stage_roof("front end (Frenet map, obstacle list)", "plan_frontend_kernel", flop_fe,
+                   "(7 M + 40) flop per point to Frenet, M = the scene's reference-line samples; the kernel "
+                   "walks outwards from the nearest abscissa instead of visiting all M"),
+    ]
+    k = pmc.get("sl_plan_narrow_kernel", {})
+    t_sl = stage_ms["SL path DP"] * 1e-3
+    sl_entry = {"kernel": "sl_plan_narrow_kernel", "stage": "SL path DP", "kernel_ms": stage_ms["SL path DP"],
+                "bound": "valu_issue", "unit": "G wave-instructions/s", "peak": ISSUE_PEAK_GINST,
+                "note": "edge costs are not materialised and the per-sample sums are collapsed into per-layer "
+                        "constants, so reference flops per edge do not describe this kernel; its bound is vector "
+                        "instruction issue"}
+    if "SQ_INSTS_VALU" in k and pmc.get("_scenarios") == B:
+        sl_entry["achieved"] = k["SQ_INSTS_VALU"] / t_sl / 1e9
+        sl_entry["frac"] = sl_entry["achieved"] / ISSUE_PEAK_GINST
+    roofs.append(sl_entry)
     n_pts = B * (sc["st_pos"].shape[1] + sc["dy_pos"].shape[1] * 11 + 1)
-    bytes_in = sum(v.nbytes for v in sc.values())
-    bytes_out = B * (8 * 3 * dims.q_max + 4 * 2)   # final x, y, speed profile, status, count
-    ms = 1e3 * elapsed / args.steps
     res = {
         "metric": "full replan plans/sec (Cartesian->Frenet + SL path DP + ST speed DP + speed profile + path in "
                   "the robot frame)",
-        "value": world * B * args.steps / elapsed, "unit": "plans/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "value": world * B * steps / sec, "unit": "plans/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms, "timed_reps": reps,
+        "ms_per_step_min": 1e3 * min(secs) / steps, "ms_per_step_max": 1e3 * max(secs) / steps,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "full pipeline: %d scenes/GPU, curved reference lines of 16-21 knots, 192 static + "
                                "64 moving obstacles (897 points to Frenet per scene), default lattice (5 lanes, "
                                "layers every 8 m), default ST grid; one mp_plan_scenes call per step" % B,
                    "scenarios_per_gpu": B, "n_l": 5, "n_st": 192, "n_dy": 64,
                    "parallelism": "scenario-sharded x%d" % world},
-        "c2f_points_per_sec": world * n_pts * args.steps / elapsed,
+        "c2f_points_per_sec": world * n_pts * steps / sec,
         "status_fractions": {"planned": float((status == 1).mean()), "no_path": float((status == 0).mean()),
                              "map_longer_than_100m": float((status == -4).mean())},
-        "roofline": {"bound": "hbm", "kernel": "whole chain (13 kernels, see profiles/ for the split)",
-                     "achieved": (bytes_in + bytes_out) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (bytes_in + bytes_out) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": bytes_in + bytes_out,
-                     "note": "algorithmic bytes = the scenes in and the plans out; every stage in between works "
-                             "from LDS-resident tables, so the chain is bound by instruction issue and latency, "
-                             "not by HBM"},
+        "stage_ms": stage_ms, "stage_ms_sum": float(sum(stage_ms.values())),
+        "roofline": max(roofs[:2], key=lambda r: r["kernel_ms"]),
+        "rooflines": roofs, "pmc_source": pmc.get("_source"),
     }
-    if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
+    if cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        n = min(args.cpu_sample, B)
-        v, dt = cpu_pipeline(sc, n, threads)
+        n = min(cpu_sample, B)
+        v, dt, cres = cpu_pipeline(sc, n, threads)
+        fx, fy, vv = (a[k][:n].cpu().numpy() for k in ("final_x", "final_y", "vv"))
+        for b, r in enumerate(cres):
+            assert (r is not None) == (status[b] == 1), "scene %d: planned/not planned differs from the oracle" % b
+            if r is not None:
+                m = len(r[1])
+                assert m == n_final[b], "scene %d: number of path points differs" % b
+                np.testing.assert_allclose(np.stack([fx[b, :m], fy[b, :m]], 1), r[0], rtol=1e-9, atol=1e-8)
+                np.testing.assert_allclose(vv[b, :m], r[1], rtol=1e-9, atol=1e-12)
         res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
                                "sample": "first %d scenes of the same batch, whole replan, C oracle driven from "
-                                         "Python, %d threads, %.1f s" % (n, threads, dt)}
-    print(json.dumps(res))
+                                         "Python, %d threads, %.1f s" % (n, threads, dt),
+                               "parity_checked": n}
+    return res
 
 
-def load_pmc():
-    """Per-kernel counter means (per launch) from the last committed rocprofv3 --pmc passes of this
-    same command; bench.py cannot collect them itself."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        k = dict(d.get("kernels", {}))
-        k["_source"] = d.get("source")
-        return k
-    except (OSError, ValueError):
-        return {}
-
-
-def cpu_baseline(sc, n_sample, threads):
-    """The CPU oracle (a quirk-exact C restatement of the reference planner) on the
-    first n_sample scenarios of the same batch, `threads` scenarios at a time."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as orc
-    orc.build()
-    orc.lib()
-
-    def one(b):
-        s_map = np.repeat(sc["s_layers"][b][:, None], N_L, axis=1)
-        l_map = np.broadcast_to(sc["l_row"][b], (N_S, N_L))
-        ob = np.stack([sc["ob_s"][b], sc["ob_l"][b]], 1)
-        r = orc.sl_find_path(s_map, l_map, int((N_L - 1) / 2), sc["ego"][b], ob, sc["ob_dist"][b],
-                             no_early_exit=True)
-        orc.st_find_speed(ST_N_T, ST_N_S, sc["down"][b], sc["up"][b], sc["n_reg"][b], float(sc["cur_vel"][b]),
-                          SPEED_LIM)
-        return r["found"]
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, range(n_sample)))
-    dt = time.perf_counter() - t0
-    return n_sample / dt, dt
-
-
+# ---------------------------------------------------------------------------
+# lattice workload
+# ---------------------------------------------------------------------------
 def materialised_roofline(sc, n, prm):
     """The two-kernel form of the same SL plan on the first n scenarios, outside the timed
     region: mp_sl_edge_cost writes every edge cost to HBM (fp64, 8 B/edge) and mp_sl_dp
     streams that tensor once -- the HBM-bound relaxation the fused kernel makes unnecessary,
-    measured so that an HBM roofline fraction below 1 is on record."""
+    measured so that an HBM roofline fraction is on record."""
     import torch
     from motion_planning_amd import batch as mb
     sb = mb.SLBatch(sc["s_layers"][:n], sc["l_row"][:n], sc["ego"][:n], sc["ob_s"][:n], sc["ob_l"][:n],
@@ -317,8 +567,6 @@ def materialised_roofline(sc, n, prm):
     edge, _ = mb.sl_edge_cost(sb, prm)
     out = mb.sl_dp(edge, prm)
     torch.cuda.synchronize()
-    # (the tests compare this path with the fused kernel bit for bit; launching the fused
-    # kernel here would mix a launch of another size into its per-kernel profile)
     assert torch.equal(out.path_idx[:, 0] >= 0, out.status == 1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     reps, t_e, t_d = 3, 0.0, 0.0
@@ -339,15 +587,256 @@ def materialised_roofline(sc, n, prm):
     traffic = None
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k and n == 1024:
         traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    del edge
     return {"bound": "hbm", "kernel": "sl_dp_kernel (relaxation over the materialised fp64 edge tensor)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": t_d, "algorithmic_bytes_per_launch": nbytes, "scenarios": n,
             "edge_kernel": {"kernel": "sl_edge_cost_kernel", "kernel_ms": t_e,
                             "written_GBps": nbytes / (t_e * 1e-3) / 1e9,
-                            "edges_per_sec": n * N_S * N_L * N_L / (t_e * 1e-3)},
-            "note": "not part of the timed step: the product path is the fused kernel (roofline / roofline_other); "
-                    "this is the same plan through mp_sl_edge_cost + mp_sl_dp, whose DP kernel reads each edge "
-                    "cost once from HBM"}
+                            "edges_evaluated_per_sec": n * N_S * N_L * N_L / (t_e * 1e-3)},
+            "note": "not part of the timed step: the product path is the fused kernel; this is the same plan "
+                    "through mp_sl_edge_cost + mp_sl_dp, whose DP kernel reads each edge cost once from HBM"}
+
+
+class H2DLoop:
+    """The same step with the host->device copy of its inputs inside: pinned host buffers,
+    two sets of device buffers, copies on a stream of their own so that the copy of step
+    i+1 runs beside the kernels of step i."""
+
+    SL_KEYS = (("s_layers", np.float64), ("l_row", np.float64), ("ego", np.float64), ("ob_s", np.float64),
+               ("ob_l", np.float64), ("n_ob", np.int32), ("ob_dist", np.float64))
+    ST_KEYS = (("st_n_s", np.int32), ("down", np.float64), ("up", np.float64), ("n_reg", np.int32),
+               ("cur_vel", np.float64))
+
+    def __init__(self, sc, prm, gather):
+        import torch
+        from motion_planning_amd import batch as mb
+        self.torch, self.mb, self.prm, self.gather = torch, mb, prm, gather
+        B = sc["s_layers"].shape[0]
+        self.host = {k: torch.from_numpy(np.ascontiguousarray(sc[k], dtype=dt)).pin_memory()
+                     for k, dt in self.SL_KEYS + self.ST_KEYS}
+        self.bytes = sum(t.numel() * t.element_size() for t in self.host.values())
+        self.copy_stream = torch.cuda.Stream()
+        self.sets = []
+        for _ in range(2):
+            d = {k: torch.empty_like(t, device="cuda") for k, t in self.host.items()}
+            sb = mb.SLBatch(d["s_layers"], d["l_row"], d["ego"], d["ob_s"], d["ob_l"], d["n_ob"], d["ob_dist"],
+                            check=False)
+            self.sets.append(dict(dev=d, sb=sb, out=mb.SLPlanOut(B, N_S, N_L, want_maps=False), st=None,
+                                  copied=torch.cuda.Event(), done=torch.cuda.Event()))
+        self.k = 0
+
+    def step(self, _i=None):
+        torch, mb = self.torch, self.mb
+        s = self.sets[self.k & 1]
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.copy_stream):
+            if self.k >= 2:
+                self.copy_stream.wait_event(s["done"])   # the kernels that read this buffer set two steps ago
+            for k, t in self.host.items():
+                s["dev"][k].copy_(t, non_blocking=True)
+            s["copied"].record(self.copy_stream)
+        main.wait_event(s["copied"])
+        d = s["dev"]
+        mb.sl_plan(s["sb"], self.prm, s["out"])
+        s["st"] = mb.st_dp(d["st_n_s"], d["down"], d["up"], d["n_reg"], d["cur_vel"], SPEED_LIM, want_tables=False,
+                           n_s_max=ST_N_S, out=s["st"])
+        s["done"].record(main)
+        o = s["out"]
+        self.gather.submit(o.path_idx, o.status, o.layers_done, o.best_cost, s["st"]["path_s_ind"], s["st"]["path_len"])
+        self.k += 1
+        return s
+
+
+def bench_lattice(args, job):
+    import torch
+    from motion_planning_amd import batch as mb, dist as mdist
+
+    world, rank, B = job.world, job.rank, job.B
+    sc = make_scenarios(job.lo, B)
+    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
+    prm = mb.sl_params(early_exit=bool(args.early_exit), n_l=N_L)
+    out = mb.SLPlanOut(B, N_S, N_L, want_maps=bool(args.maps))
+    st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
+                 n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
+    gather = ResultGather(world, job.backend, B, job.rows, N_S, ST_N_T)
+    steps, reps = args.steps, args.reps
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+            torch.cuda.Event(enable_timing=True)) for _ in range(steps)] for _ in range(reps)]
+    state = dict(st=None, rep=-1)
+
+    def step(i=None):
+        e = ev[state["rep"]][i] if i is not None and state["rep"] >= 0 else None
+        if e:
+            e[0].record()
+        mb.sl_plan(sb, prm, out)
+        if e:
+            e[1].record()
+        state["st"] = mb.st_dp(st_in["n_s"], st_in["s_down"], st_in["s_up"], st_in["n_reg"], st_in["cur_vel"],
+                               SPEED_LIM, want_tables=bool(args.maps), n_s_max=ST_N_S, out=state["st"])
+        if e:
+            e[2].record()
+        st = state["st"]
+        gather.submit(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"], st["path_len"])
+
+    for _ in range(args.warmup):
+        step()
+    gather.drain()
+    secs = []
+    for r in range(reps):      # each block: barrier + sync, exactly `steps` steps, drain, barrier + sync
+        state["rep"] = r
+        secs += timed_blocks(job, step, gather.drain, steps, 1)
+    state["rep"] = -1
+    st = state["st"]
+
+    sl_all = [e[0].elapsed_time(e[1]) for blk in ev for e in blk]
+    st_all = [e[1].elapsed_time(e[2]) for blk in ev for e in blk]
+    sl_ms, st_ms = float(np.mean(sl_all)), float(np.mean(st_all))
+    layers = out.layers_done.cpu().numpy().astype(np.int64)
+    edges_nominal = int(np.sum(N_L + (layers - 1) * N_L * N_L))
+    found_frac = float((out.status == 1).float().mean())
+    bad = int(((out.status != 1) & (out.status != 0)).sum())
+    assert bad == 0, "kernel reported %d scenarios with an error status" % bad
+    assert int(st["path_len"].min()) >= 2
+
+    if job.dist_on:
+        # every rank holds every scenario's record, in scenario order
+        u = mdist.unpack_results(gather.rows_of(rank, B).to("cuda"), N_S, ST_N_T)
+        assert torch.equal(u["path_idx"], out.path_idx) and torch.equal(u["st_path"], st["path_s_ind"])
+        assert torch.equal(u["status"], out.status) and torch.equal(u["best_cost"].isnan(), out.best_cost.isnan())
+        n_all = 0
+        for r in range(world):
+            lo, hi = (mdist.shard_range(job.total, r, world) if job.scaling == "strong"
+                      else (r * B, (r + 1) * B))
+            n_all += int((mdist.unpack_results(gather.rows_of(r, hi - lo), N_S, ST_N_T)["st_len"] >= 2).sum())
+        assert n_all == job.total, "gathered %d complete records of %d" % (n_all, job.total)
+
+    # the step again with the host->device copies of its inputs inside (never `value`)
+    h2d = None
+    if args.h2d_reps > 0:
+        loop = H2DLoop(sc, prm, gather)
+        for _ in range(max(2, args.warmup)):
+            loop.step()
+        gather.drain()
+        hsecs = timed_blocks(job, loop.step, gather.drain, steps, args.h2d_reps)
+        last = loop.sets[(loop.k - 1) & 1]
+        torch.cuda.synchronize()
+        assert torch.equal(last["out"].path_idx, out.path_idx) and torch.equal(last["st"]["path_s_ind"],
+                                                                              st["path_s_ind"])
+        h2d = (hsecs, loop.bytes)
+
+    # edges the fused kernel really prices (counting instance, outside the timed region)
+    edges_eval = None
+    if rank == 0 and not args.early_exit:
+        cnt_out = mb.SLPlanOut(B, N_S, N_L, want_maps=False)
+        _, edges_eval = mb.sl_plan_counted(sb, prm, cnt_out)
+        assert torch.equal(cnt_out.path_idx, out.path_idx) and torch.equal(cnt_out.status, out.status)
+
+    if rank != 0:
+        return None
+    sec = float(np.median(secs))
+    plans_per_s = job.total * steps / sec
+    k_samples = 4  # samples per edge at a 1.5 m layer gap and 0.5 m spacing
+    # algorithmic work per unit, as the reference writes it (1 flop per add/mul/sqrt/compare)
+    flop_edge = 45 + k_samples * (50 + 7 * N_OB)      # one SL edge
+    st_edges = B * (ST_N_S + (ST_N_T - 2) * ST_N_S * (ST_N_S + 1) // 2)  # ST edges per launch
+    flop_st = float(30 + 9 * ST_R) * st_edges
+    st_bytes = B * (16.0 * ST_N_T * ST_R + 4.0 * ST_N_T)  # interval bounds in, path out
+    pmc = load_pmc()
+    pmc_ok = pmc.get("_scenarios") == B    # the counters are per launch of the profiled batch size
+
+    def traffic_of(kernel):
+        k = pmc.get(kernel, {})
+        return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 if pmc_ok and "FETCH_SIZE" in k and "WRITE_SIZE" in k else None
+
+    def issue_of(kernel, ms):
+        k = pmc.get(kernel, {})
+        return k["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9 if pmc_ok and "SQ_INSTS_VALU" in k else None
+
+    st_tf = flop_st / (st_ms * 1e-3) / 1e12
+    st_issue = issue_of("st_dp_kernel", st_ms)
+    roof_st = {"bound": "valu", "kernel": "st_dp_kernel<false> (speed DP over the ST grid)",
+               "achieved": st_tf, "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s", "frac": st_tf / VALU_FP64_PEAK_TF,
+               "traffic": traffic_of("st_dp_kernel"), "kernel_ms": st_ms,
+               "algorithmic_flop_per_launch": flop_st, "st_edges_per_launch": st_edges,
+               "no_fma_ceiling": VALU_FP64_NO_FMA_TF, "frac_of_no_fma_ceiling": st_tf / VALU_FP64_NO_FMA_TF,
+               "issue_slots_used": st_issue / ISSUE_PEAK_GINST if st_issue else None,
+               "hbm": {"achieved": st_bytes / (st_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": st_bytes / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": st_bytes},
+               "note": "75 flop per ST edge (30 + 9 R, R = 5) x every edge of the grid, against the fp64 vector "
+                       "peak, which counts a fused multiply-add as two: results must equal Python's bit for bit, "
+                       "so no multiply-add is fused and the reachable ceiling is 39.3 TFLOP/s "
+                       "(frac_of_no_fma_ceiling); tables live in LDS, HBM traffic is the interval bounds in and "
+                       "the path out (hbm: ~0 by design)"}
+    sl_issue = issue_of("sl_plan_kernel", sl_ms)
+    roof_sl = {"bound": "valu_issue", "kernel": "sl_plan_kernel<true,false> (fused edge cost + DP relaxation)",
+               "achieved": sl_issue, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+               "frac": sl_issue / ISSUE_PEAK_GINST if sl_issue else None,
+               "traffic": traffic_of("sl_plan_kernel"), "kernel_ms": sl_ms,
+               "edge_costs": "not materialised", "workgroups_per_cu": 8, "waves_per_simd": 4,
+               "us_per_layer_per_launch": 1e3 * sl_ms / N_S,
+               "edges_evaluated_per_launch": edges_eval,
+               "edges_evaluated_per_sec": edges_eval / (sl_ms * 1e-3) if edges_eval else None,
+               "evaluated_fraction_of_lattice": edges_eval / edges_nominal if edges_eval else None,
+               "lattice_edges_nominal_per_launch": edges_nominal,
+               "reference_flop_per_edge": flop_edge,
+               "note": "the kernel keeps edge costs on chip, collapses the per-sample sums into per-layer "
+                       "constants and prunes exactly, so neither 8 B nor 1645 flop per lattice edge describe its "
+                       "work; it is bound by vector instruction issue and per-layer latency: frac = its own "
+                       "vector instructions (SQ_INSTS_VALU of the committed counter pass) / duration against "
+                       "1024 SIMDs x 2.4 GHz / 4 cycles.  The HBM-bound form of the same plan is "
+                       "roofline_materialised."}
+    dominant = roof_sl if sl_ms >= st_ms else roof_st
+    res = {
+        "metric": "SL+ST DP plans/sec (quintic lattice edges/sec: edges_evaluated_per_sec and "
+                  "lattice_edges_nominal_per_sec)",
+        "value": plans_per_s, "unit": "plans/s", "n_gpus": world, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * sec / steps, "timed_reps": reps,
+        "ms_per_step_min": 1e3 * min(secs) / steps, "ms_per_step_max": 1e3 * max(secs) / steps,
+        "higher_is_better": True, "scaling": job.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "batched SL path DP %d scenarios over %d GPU(s) x (64 s-layers x 128 l-samples, "
+                               "50 obstacles), every layer relaxed, + ST speed DP 11x97 with 5 blocked "
+                               "intervals per layer; RCCL all-gather of results when n_gpus > 1"
+                               % (job.total, world),
+                   "total_scenarios": job.total, "scenarios_rank0": B, "n_s": N_S, "n_l": N_L, "n_ob": N_OB,
+                   "st_n_t": ST_N_T, "st_n_s": ST_N_S, "st_regions": ST_R, "early_exit": bool(args.early_exit),
+                   "maps_written": bool(args.maps), "backend": job.backend if job.dist_on else None,
+                   "parallelism": "scenario-sharded x%d" % world},
+        "edges_evaluated_per_sec": world * edges_eval / (sl_ms * 1e-3) if edges_eval else None,
+        "lattice_edges_nominal_per_sec": world * edges_nominal / (sl_ms * 1e-3),
+        "sl_kernel_ms": sl_ms, "st_kernel_ms": st_ms, "found_fraction": found_frac,
+        "roofline": dominant,
+        "roofline_other": roof_st if dominant is roof_sl else roof_sl,
+        "pmc_source": pmc.get("_source"),
+    }
+    if h2d:
+        hsecs, nbytes = h2d
+        hsec = float(np.median(hsecs))
+        res["value_with_h2d"] = job.total * steps / hsec
+        res["h2d"] = {"ms_per_step": 1e3 * hsec / steps, "bytes_per_step_rank0": nbytes,
+                      "copy_only_ms_at_63GBps": nbytes / 63e9 * 1e3,
+                      "note": "same step, inputs copied from pinned host memory inside it on a copy stream, "
+                              "double-buffered so the copy of step i+1 runs beside the kernels of step i"}
+    if args.materialised > 0 and world == 1:
+        res["roofline_materialised"] = materialised_roofline(sc, min(args.materialised, B), prm)
+    if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        n = min(args.cpu_sample, B)
+        v, dt, cres = cpu_baseline(sc, n, threads)
+        res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
+                               "sample": "first %d scenarios of the same batch (SL every layer + ST), "
+                                         "C oracle, %d threads, %.1f s" % (n, threads, dt),
+                               "reference_python": {"value": 1.0 / 1500.0, "unit": "plans/s", "cores": 1,
+                                                    "note": "the reference itself, timed in the build container "
+                                                            "only (its source does not travel): ~368 us per SL "
+                                                            "edge -> ~25 min per 64x128x50 plan, plus 0.4 s per "
+                                                            "ST plan of 101 cells"}}
+        if not args.early_exit and not args.maps:
+            ties = check_lattice_parity(cres, out, st)
+            res["cpu_baseline"]["parity_checked"] = n
+            res["cpu_baseline"]["parity_ties"] = ties
+    return res
 
 
 def main():
@@ -355,7 +844,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenarios", type=int, default=4096, help="scenarios per GPU")
+    ap.add_argument("--reps", type=int, default=15, help="timed blocks of --steps steps; the median is reported")
+    ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (weak scaling)")
+    ap.add_argument("--total-scenarios", type=int, default=None,
+                    help="scenarios split over all GPUs (strong scaling; default 65536 when --gpus > 1)")
     ap.add_argument("--workload", choices=["lattice", "pipeline"], default="lattice",
                     help="lattice: batched SL path DP (64x128 lattice, 50 obstacles) + ST speed DP; "
                          "pipeline: the whole replan on curved reference lines with 256 obstacles")
@@ -365,168 +857,34 @@ def main():
     ap.add_argument("--materialised", type=int, default=1024,
                     help="scenarios run through the two-kernel SL path for its HBM roofline (0 = skip)")
     ap.add_argument("--maps", type=int, default=0, help="1 = also write cost_map/index_map/ST tables to HBM")
+    ap.add_argument("--h2d-reps", type=int, default=5, help="timed blocks of the host-to-device variant (0 = skip)")
+    ap.add_argument("--pipeline-steps", type=int, default=10,
+                    help="steps per timed block of the whole-replan leg attached to the lattice line (0 = skip)")
+    ap.add_argument("--pipeline-scenes", type=int, default=4096, help="scenes per GPU of the whole-replan workload")
+    ap.add_argument("--pipeline-cpu-sample", type=int, default=256)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="exercise the launcher, the sharding and the result exchange only (CPU, gloo; no kernels)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from motion_planning_amd import batch as mb, dist as mdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    # MP_BENCH_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks
-    # share the card and the gather is staged through host memory)
-    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    if exchange_on(world):
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-            os.environ.setdefault(k, v)   # a forced one-rank job started without a launcher
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
-    if args.workload == "pipeline":
-        bench_pipeline(args, world, rank, backend)
-        if exchange_on(world):
-            dist.destroy_process_group()
+    job = Job(args)
+    if args.launch_check:
+        launch_check(job)
+        job.close()
         return
-    B = args.scenarios
-    sc = make_scenarios(rank * B, B)
-    sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
-    prm = mb.sl_params(early_exit=bool(args.early_exit), n_l=N_L)
-    out = mb.SLPlanOut(B, N_S, N_L, want_maps=bool(args.maps))
-    st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
-                 n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
-    gather = ResultGather(world, backend, B, N_S, ST_N_T)
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        mb.sl_plan(sb, prm, out)
-        if i is not None:
-            ev[i][1].record()
-        st = mb.st_dp(st_in["n_s"], st_in["s_down"], st_in["s_up"], st_in["n_reg"], st_in["cur_vel"], SPEED_LIM,
-                      want_tables=bool(args.maps), n_s_max=ST_N_S)
-        if i is not None:
-            ev[i][2].record()
-        gather.submit(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"], st["path_len"])
-        return st
-
-    def fence():
-        torch.cuda.synchronize()
-        if exchange_on(world):
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    gather.drain()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        st = step(i)
-    gather.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if exchange_on(world):
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-
-    sl_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    st_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    layers = out.layers_done.cpu().numpy().astype(np.int64)
-    edges_launch = int(np.sum(N_L + (layers - 1) * N_L * N_L))
-    found_frac = float((out.status == 1).float().mean())
-    bad = int(((out.status != 1) & (out.status != 0)).sum())
-    assert bad == 0, "kernel reported %d scenarios with an error status" % bad
-    assert int(st["path_len"].min()) >= 2
-
-    if exchange_on(world):
-        # every rank holds every scenario's record, in scenario order
-        gathered = gather.last()
-        u = mdist.unpack_results(gathered[rank * B:(rank + 1) * B].to("cuda"), N_S, ST_N_T)
-        assert torch.equal(u["path_idx"], out.path_idx) and torch.equal(u["st_path"], st["path_s_ind"])
-        assert torch.equal(u["status"], out.status) and torch.equal(u["best_cost"].isnan(), out.best_cost.isnan())
-        assert int((mdist.unpack_results(gathered, N_S, ST_N_T)["st_len"] >= 2).sum()) == world * B
-    if rank == 0:
-        plans_per_s = world * B * args.steps / elapsed
-        edges_per_s = edges_launch / (sl_ms * 1e-3)
-        k_samples = 4  # samples per edge at a 1.5 m layer gap and 0.5 m spacing
-        # algorithmic work per unit, as the reference writes it (1 flop per add/mul/sqrt/compare)
-        flop_edge = 45 + k_samples * (50 + 7 * N_OB)      # one SL edge
-        sl_bytes = 8.0 * edges_launch                     # 4 B written + 4 B read per edge if materialised
-        st_edges = B * (ST_N_S + (ST_N_T - 2) * ST_N_S * (ST_N_S + 1) // 2)  # ST edges per launch
-        flop_st_edge = 30 + 9 * ST_R                      # one ST edge
-        st_bytes = B * (16.0 * ST_N_T * ST_R + 4.0 * ST_N_T)  # interval bounds in, path out
-        pmc = load_pmc()
-
-        def roof(kernel, label, ms, alg_bytes, alg_flop, note):
-            k = pmc.get(kernel, {})
-            traffic = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in k and "WRITE_SIZE" in k else None
-            gbs = alg_bytes / (ms * 1e-3) / 1e9
-            tf = alg_flop / (ms * 1e-3) / 1e12
-            r = {"bound": "hbm", "kernel": label, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms,
-                 "algorithmic_bytes_per_launch": alg_bytes,
-                 "valu": {"achieved": tf, "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s (fp64 vector)",
-                          "frac": tf / VALU_FP64_PEAK_TF, "algorithmic_flop_per_launch": alg_flop},
-                 "note": note}
-            if "SQ_INSTS_VALU" in k:
-                # share of the chip's vector issue slots the kernel's own instructions filled:
-                # 4 cycles per wave64 instruction, 1024 SIMDs, nominal 2.4 GHz
-                r["valu"]["issue_slots_used"] = k["SQ_INSTS_VALU"] * 4.0 / (1024 * ms * 1e-3 * 2.4e9)
-            return r
-
-        roof_sl = roof("sl_plan_kernel", "sl_plan_kernel (fused edge cost + DP relaxation)", sl_ms, sl_bytes,
-                       float(flop_edge) * edges_launch,
-                       "algorithmic bytes = 8 B/edge (edge cost written once and read once if materialised) and "
-                       "1645 flop/edge as the reference writes them; the fused kernel keeps edge costs on chip, "
-                       "collapses the per-sample sums into per-layer constants and prunes exactly, so both "
-                       "fractions exceed 1: the kernel is bound by instruction latency per layer, not by HBM or "
-                       "flops (traffic = measured FETCH_SIZE+WRITE_SIZE per launch, 8-byte-per-lane accesses, "
-                       "uncorrected)")
-        roof_st = roof("st_dp_kernel", "st_dp_kernel (speed DP over the ST grid)", st_ms, st_bytes,
-                       float(flop_st_edge) * st_edges,
-                       "tables live in LDS: HBM traffic is the interval bounds in and the path out, so the HBM "
-                       "fraction is ~0 by design; the bound that matters is the fp64 vector rate (valu)")
-        dominant = roof_sl if sl_ms >= st_ms else roof_st
-        res = {
-            "metric": "SL+ST DP plans/sec (quintic lattice edges/sec in edges_per_sec)",
-            "value": plans_per_s, "unit": "plans/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batched SL path DP 4096 scenarios/GPU x (64 s-layers x 128 l-samples, "
-                                   "50 obstacles), every layer relaxed, + ST speed DP 11x97 with 5 blocked "
-                                   "intervals per layer; RCCL all-gather of results when n_gpus > 1",
-                       "scenarios_per_gpu": B, "n_s": N_S, "n_l": N_L, "n_ob": N_OB, "st_n_t": ST_N_T,
-                       "st_n_s": ST_N_S, "st_regions": ST_R, "early_exit": bool(args.early_exit),
-                       "maps_written": bool(args.maps), "parallelism": "scenario-sharded x%d" % world},
-            "edges_per_sec": edges_per_s * world, "edges_per_launch": edges_launch,
-            "sl_kernel_ms": sl_ms, "st_kernel_ms": st_ms, "found_fraction": found_frac,
-            "roofline": dominant,
-            "roofline_other": roof_st if dominant is roof_sl else roof_sl,
-            "pmc_source": pmc.get("_source"),
-        }
-        if args.materialised > 0 and world == 1:
-            res["roofline_materialised"] = materialised_roofline(sc, min(args.materialised, B), prm)
-        if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
-            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-            v, dt = cpu_baseline(sc, min(args.cpu_sample, B), threads)
-            res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
-                                   "sample": "first %d scenarios of the same batch (SL every layer + ST), "
-                                             "C oracle, %d threads, %.1f s" % (min(args.cpu_sample, B), threads, dt)}
+    if args.workload == "pipeline":
+        res = bench_pipeline(args, job, args.steps, args.warmup, max(1, args.reps), args.cpu_sample)
+    else:
+        res = bench_lattice(args, job)
+        if args.pipeline_steps > 0:
+            pipe = bench_pipeline(args, job, args.pipeline_steps, 2, 5, args.pipeline_cpu_sample)
+            if res is not None:
+                res["pipeline"] = pipe
+    if job.rank == 0:
         print(json.dumps(res))
-    if exchange_on(world):
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

@@ -119,6 +119,16 @@ int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cos
                int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
                double *best_cost, void *stream);
 
+/* Measurement aid, no counterpart in the reference: mp_sl_plan (maps not
+ * written) by an instance of the same kernel that also counts the lattice edges
+ * it actually prices -- exact pruning skips most of the n_l + (n_s-1)*n_l^2 edges
+ * of a plan -- and ADDS that count, summed over the batch, to *n_evaluated (one
+ * device uint64 the caller zeroes).  Lattices of more than 16 lanes only (the
+ * narrow kernel prices every edge).  Results are identical to mp_sl_plan's. */
+int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
+                       int32_t *status, int32_t *layers_done, double *best_cost, uint64_t *n_evaluated,
+                       void *stream);
+
 /* Replaces PathPlanner.cal_cost + get_path (path_planner.py:104-155) for every
  * lattice edge: edge_cost[B][n_s][n_l(to)][n_l(from)]; layer 0 holds the ego
  * edge in [..][to][0] and NaN elsewhere.  status as above (no FOUND/NOT_FOUND:
@@ -363,6 +373,16 @@ int64_t mp_plan_arena_bytes(const mp_plan_dims *dims);
  * can be captured in a HIP graph. */
 int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                    void *arena, int64_t arena_bytes, void *stream);
+
+/* Measurement aid, no counterpart in the reference: mp_plan_scenes with a HIP
+ * event between its MP_PLAN_N_STAGES stages.  Blocks until the chain has run and
+ * writes each stage's duration in milliseconds to stage_ms[MP_PLAN_N_STAGES]
+ * (HOST memory); mp_plan_stage_name(i) names stage i.  Results in the arena as
+ * from mp_plan_scenes.  Not for graph capture (creates and waits on events). */
+#define MP_PLAN_N_STAGES 13
+const char *mp_plan_stage_name(int32_t i);
+int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
+                         void *arena, int64_t arena_bytes, void *stream, float *stage_ms);
 
 /* ---- whole replan without a caller-owned arena ------------------------------
  * No counterpart in the reference.  For callers that cannot allocate device

@@ -51,6 +51,7 @@ class PlanResult(C.Structure):       # mp_plan_result
 
 
 MP_PLAN_STATIC_BYTES = 32 << 20
+MP_PLAN_N_STAGES = 13
 
 
 class PlanParams(C.Structure):       # mp_plan_params
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mp_last_error": (C.c_char_p, []),
     "mp_set_knob": (C.c_int, [C.c_char_p, C.c_int32]),
     "mp_sl_plan": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 7),
+    "mp_sl_plan_counted": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 6),
     "mp_sl_edge_cost": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams), _vp, _vp, _vp]),
     "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, _vp, C.POINTER(SlParams)] + [_vp] * 7),
     "mp_st_dp": (C.c_int, [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp] + [C.c_double] * 3 + [_vp] * 5),
@@ -90,6 +92,9 @@ SIGNATURES = {
     "mp_plan_arena_bytes": (C.c_int64, [C.POINTER(PlanDims)]),
     "mp_plan_scenes_static": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams),
                                         C.POINTER(PlanResult), _vp]),
+    "mp_plan_stage_name": (C.c_char_p, [C.c_int32]),
+    "mp_plan_scenes_timed": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp,
+                                       C.c_int64, _vp, C.POINTER(C.c_float)]),
     "mp_plan_scenes": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp, C.c_int64,
                                  _vp]),
 }

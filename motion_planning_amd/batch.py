@@ -112,6 +112,20 @@ def sl_plan(batch, params=None, out=None, want_maps=True):
     return out
 
 
+def sl_plan_counted(batch, params=None, out=None):
+    """mp_sl_plan through the counting instance of the fused kernel (measurement aid):
+    returns (out, edges the kernel priced over the whole batch).  Reads the counter back,
+    so it synchronises."""
+    params = params or sl_params(n_l=batch.n_l)
+    out = out or SLPlanOut(batch.B, batch.n_s, batch.n_l, False)
+    n_eval = torch.zeros(1, dtype=torch.int64, device=batch.s_layers.device)
+    cs = batch.c_struct()
+    check(lib().mp_sl_plan_counted(C.byref(cs), C.byref(params), _p(out.path_idx), _p(out.status),
+                                   _p(out.layers_done), _p(out.best_cost), _p(n_eval), _stream()),
+          "mp_sl_plan_counted")
+    return out, int(n_eval.item())
+
+
 def sl_edge_cost(batch, params=None):
     """Every lattice edge cost (replaces PathPlanner.cal_cost, path_planner.py:104-130).
 
@@ -137,11 +151,12 @@ def sl_dp(edge_cost, params, out=None, n_layers=None):
     return out
 
 
-def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tables=True, n_s_max=None):
+def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tables=True, n_s_max=None, out=None):
     """ST speed DP (replaces SpeedPlanner.find_speed, speed_planner.py:57-162).
 
     n_s [B]; s_down / s_up [B, n_t, r_max]; n_reg [B, n_t]; cur_vel [B].
-    Returns dict(cost, pre, path_s_ind [B, n_t], path_len [B])."""
+    Returns dict(cost, pre, path_s_ind [B, n_t], path_len [B]); `out` (a dict returned by
+    an earlier call of the same shape) is written in place instead of allocating."""
     n_s = to_dev(n_s, torch.int32)
     n_reg = to_dev(n_reg, torch.int32)
     B, n_t = n_reg.shape
@@ -151,10 +166,14 @@ def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tab
     cur_vel = to_dev(cur_vel)
     N = int(n_s_max if n_s_max is not None else n_s.max())
     dev = n_s.device
-    cost = torch.empty((B, n_t, N), dtype=torch.float64, device=dev) if want_tables else None
-    pre = torch.empty((B, n_t, N), dtype=torch.int32, device=dev) if want_tables else None
-    idx = torch.empty((B, n_t), dtype=torch.int32, device=dev)
-    plen = torch.empty(B, dtype=torch.int32, device=dev)
+    if out is not None:
+        cost, pre, idx, plen = out["cost"], out["pre"], out["path_s_ind"], out["path_len"]
+        assert idx.shape == (B, n_t) and plen.shape == (B,) and (cost is None or cost.shape == (B, n_t, N))
+    else:
+        cost = torch.empty((B, n_t, N), dtype=torch.float64, device=dev) if want_tables else None
+        pre = torch.empty((B, n_t, N), dtype=torch.int32, device=dev) if want_tables else None
+        idx = torch.empty((B, n_t), dtype=torch.int32, device=dev)
+        plen = torch.empty(B, dtype=torch.int32, device=dev)
     check(lib().mp_st_dp(B, n_t, N, _p(n_s), _p(s_down), _p(s_up), _p(n_reg), r_max, _p(cur_vel),
                          float(speed_lim), float(ds), float(dt), _p(cost), _p(pre), _p(idx), _p(plen),
                          _stream()), "mp_st_dp")

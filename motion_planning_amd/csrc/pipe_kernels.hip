@@ -479,7 +479,8 @@ static int pipe_launch_check(const char *what)
 }
 
 static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
-                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out);
+                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out,
+                            hipEvent_t *stage_ev = nullptr);
 
 extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                               void *arena, int64_t arena_bytes, void *stream)
@@ -487,8 +488,11 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
     return plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr);
 }
 
+// stage_ev: null, or MP_PLAN_N_STAGES + 1 events; event 0 is recorded before the first
+// stage and event i + 1 behind stage i (mp_plan_scenes_timed).
 static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
-                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out)
+                            void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out,
+                            hipEvent_t *stage_ev)
 {
     int rc = check_dims(dims);
     if (rc) return rc;
@@ -531,18 +535,32 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
     const int mid_l = p.sl.mid_l >= 0 ? p.sl.mid_l : (int)((d.n_l - 1) / 2);
     if (mid_l >= d.n_l) { mp_set_error("mid_l out of range"); return MP_E_BADARG; }
 
+    int stage_no = 0;
+#define PLAN_STAGE_DONE()                                                                         \
+    do {                                                                                          \
+        if (stage_ev && hipEventRecord(stage_ev[++stage_no], st) != hipSuccess) {                 \
+            mp_set_error("mp_plan_scenes_timed: hipEventRecord failed");                          \
+            return MP_E_LAUNCH;                                                                   \
+        }                                                                                         \
+    } while (0)
+    if (stage_ev && hipEventRecord(stage_ev[0], st) != hipSuccess) {
+        mp_set_error("mp_plan_scenes_timed: hipEventRecord failed");
+        return MP_E_LAUNCH;
+    }
     // result rows whose tails nobody writes start from zero ("zeros" doubles as the ego
     // position (0, 0) and as the path spline's end slope)
     if (hipMemsetAsync(arena, 0, (size_t)tab[PLAN_N_ZEROED].offset, st) != hipSuccess) {
         mp_set_error("mp_plan_scenes: memset failed");
         return MP_E_LAUNCH;
     }
+    PLAN_STAGE_DONE();
 
     // 1. Frenet frame of every scene, the ego at the robot frame's origin
     rc = mp_refline_tables(B, in.knots_x, in.knots_y, in.n_knots, d.n_knots_max, in.line_vec, o.zeros, p.d_x,
                            d.m_max, o.tab_x, o.tab_y, o.tab_s, o.tab_theta, o.tab_kappa, o.tab_m, o.origin,
                            o.rl_status, o.inv_x, o.inv_s, o.inv_y, o.inv_theta, o.n_inv, stream);
     if (rc) return rc;
+    PLAN_STAGE_DONE();
 
     // 2. ego state, layers, obstacle frames to Frenet, obstacle list
     {
@@ -565,6 +583,7 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         rc = pipe_launch_check("mp_plan_scenes (front end)");
         if (rc) return rc;
     }
+    PLAN_STAGE_DONE();
 
     GlueDev g;
     g.d = d;
@@ -598,41 +617,92 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
                         stream);
         if (rc) return rc;
     }
+    PLAN_STAGE_DONE();
     // 4. knots of the path spline, 5. the path every path_dt
     hipLaunchKernelGGL(plan_knots_kernel, per_scene, blk, 0, st, g);
     rc = pipe_launch_check("mp_plan_scenes (path knots)");
     if (rc) return rc;
+    PLAN_STAGE_DONE();
     const double *zero_vec = o.zeros; // end slope 0.0 (path_planner.py:53)
     rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 0, nullptr, nullptr,
                        d.p_max, o.path_s, o.path_l, nullptr, o.n_path, o.path_status, stream);
     if (rc) return rc;
+    PLAN_STAGE_DONE();
 
     // 6. ST grid width, 7. blocked intervals, 8. speed search
     hipLaunchKernelGGL(plan_stdims_kernel, per_scene, blk, 0, st, g);
     rc = pipe_launch_check("mp_plan_scenes (ST grid)");
     if (rc) return rc;
+    PLAN_STAGE_DONE();
     rc = mp_st_regions_strided(B, d.n_t, o.path_s, o.path_l, o.n_path, d.p_max, o.st_s, o.st_l, in.st_rad, in.n_st,
                                d.n_st_max, o.dy_s, o.dy_l, in.dy_rad, in.n_dy, d.n_dy_max, d.n_frames, d.r_max,
                                o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream);
     if (rc) return rc;
+    PLAN_STAGE_DONE();
     rc = mp_st_dp(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
                   p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len, stream);
     if (rc) return rc;
+    PLAN_STAGE_DONE();
 
     // 9. speed profile every dt/5, 10. path points at its arc lengths, 11. back to the robot frame
     hipLaunchKernelGGL(plan_speed_kernel, per_scene, blk, 0, st, g);
     rc = pipe_launch_check("mp_plan_scenes (speed knots)");
     if (rc) return rc;
+    PLAN_STAGE_DONE();
     const double curve_dt = p.st_dt * 1.0 / 5; // speed_planner.py:22
     rc = mp_curve_eval(B, o.sp_t, o.sp_s, o.st_path_len, d.n_t, o.robot_vel, curve_dt, 1, nullptr, nullptr, d.q_max,
                        o.prof_t, o.ss, o.vv, o.n_prof, o.prof_status, stream);
     if (rc) return rc;
+    PLAN_STAGE_DONE();
     rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 2, o.ss, o.n_prof,
                        d.q_max, o.final_s, o.final_l, nullptr, o.n_final, o.final_status, stream);
     if (rc) return rc;
-    return mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
-                       o.inv_theta, o.n_inv, o.final_x, o.final_y, o.status, o.prof_status, o.final_status,
-                       o.n_prof, stream);
+    PLAN_STAGE_DONE();
+    rc = mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
+                     o.inv_theta, o.n_inv, o.final_x, o.final_y, o.status, o.prof_status, o.final_status,
+                     o.n_prof, stream);
+    if (rc) return rc;
+    PLAN_STAGE_DONE();
+#undef PLAN_STAGE_DONE
+    if (stage_ev && stage_no != MP_PLAN_N_STAGES) {
+        mp_set_error("mp_plan_scenes_timed: %d stages recorded, %d expected", stage_no, MP_PLAN_N_STAGES);
+        return MP_E_LAUNCH;
+    }
+    return MP_OK;
+}
+
+static const char *const g_stage_names[MP_PLAN_N_STAGES] = {
+    "clear result rows (memset)", "reference-line tables", "front end (Frenet map, obstacle list)",
+    "SL path DP", "path spline knots", "path sampling", "ST grid width", "ST blocked intervals", "ST speed DP",
+    "speed spline knots", "speed profile", "path points at the profile", "Frenet to Cartesian"};
+
+extern "C" const char *mp_plan_stage_name(int32_t i)
+{
+    return (i >= 0 && i < MP_PLAN_N_STAGES) ? g_stage_names[i] : nullptr;
+}
+
+extern "C" int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims,
+                                    const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream,
+                                    float *stage_ms)
+{
+    if (!stage_ms) { mp_set_error("mp_plan_scenes_timed: null stage_ms"); return MP_E_BADARG; }
+    hipEvent_t ev[MP_PLAN_N_STAGES + 1];
+    int made = 0;
+    int rc = MP_OK;
+    for (; made <= MP_PLAN_N_STAGES; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) { mp_set_error("hipEventCreate failed"); rc = MP_E_LAUNCH; break; }
+    if (!rc) rc = plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr, ev);
+    if (!rc && hipEventSynchronize(ev[MP_PLAN_N_STAGES]) != hipSuccess) {
+        mp_set_error("mp_plan_scenes_timed: hipEventSynchronize failed");
+        rc = MP_E_LAUNCH;
+    }
+    for (int i = 0; !rc && i < MP_PLAN_N_STAGES; ++i)
+        if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) {
+            mp_set_error("mp_plan_scenes_timed: hipEventElapsedTime failed");
+            rc = MP_E_LAUNCH;
+        }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -46,6 +46,7 @@ struct SlDev {
     double *best_cost;
     double *edge_cost; // edge-tensor kernel only
     int32_t pair_cap;  // fused kernel: (sample, obstacle) pairs the LDS pair store holds per scenario
+    unsigned long long *n_evaluated; // counting instance of the fused kernel only: edges priced, summed over the batch
 };
 
 struct LayerGeom {
@@ -440,10 +441,11 @@ struct SrcSh {
 // predecessor first, then outward walks that stop once cS*H*dl^2 alone exceeds
 // the best cost so far.  w_inv = 1/(cS*H) with its safety factor, or 0 when
 // the bound does not apply.  Returns the accumulated cost; *bj_out = predecessor.
-template <int NE, bool BOUND_FIRST = false>
+// COUNT: *n_eval is raised by one per edge priced (measurement build of the kernel).
+template <int NE, bool BOUND_FIRST = false, bool COUNT = false>
 __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, double l2v, double Q, double w_inv,
                                                double m_prev, double g_max, bool sorted, double pen,
-                                               const Collider<NE> &col, int *bj_out)
+                                               const Collider<NE> &col, int *bj_out, int *n_eval = nullptr)
 {
     const int l2 = threadIdx.x;
     auto eval = [&](double l1, double cp, double dl) {
@@ -456,6 +458,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     double2 lc = src.lc[j0];
     double best = eval(lc.x, lc.y, l2v - lc.x);
     int bj = j0;
+    if constexpr (COUNT) ++*n_eval;
     // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
     // m_prev + cSH*dl^2 up to rounding, which the slack terms cover
     // (the window follows `best` down: a free edge found next to a blocked one ends the walk)
@@ -469,6 +472,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     // penalty (a lower bound of its cost, since the penalty only adds and rounding is
     // monotone) and its pairs are only looked at if that bound could still win.
     auto consider = [&](int j, double l1, double cp, double dl) {
+        if constexpr (COUNT) ++*n_eval;
         const double u = l1 - src.mid;
         const double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
         double c;
@@ -553,9 +557,11 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   bookkeeping of layers without a barrier) | offL[n_s] u16 (first pair of the layer)
 //   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
 // SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
-template <bool SHARED_ROW, bool MAPS>
+// COUNT: measurement build that also adds the number of edges it priced to *a.n_evaluated
+template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
 __global__ void sl_plan_kernel(SlDev a)
 {
+    int n_eval = 0;
     if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -782,12 +788,14 @@ __global__ void sl_plan_kernel(SlDev a)
             e += hit ? pen : 0.0;
             best = e + cost_own;
             bj = tid;
+            if constexpr (COUNT) ++n_eval;
         } else if (is_target) {
 #define SL_RELAX(NE)                                                                                     \
     {                                                                                                    \
         Collider<NE> col;                                                                                \
         col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);                    \
-        best = relax_target<NE>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj);      \
+        best = relax_target<NE, false, COUNT>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj, \
+                                              &n_eval);                                                  \
     }
             switch (ent_stored ? n_ent : -1) {
             case 0: SL_RELAX(0) break;
@@ -802,7 +810,8 @@ __global__ void sl_plan_kernel(SlDev a)
                 if (n_ent > 24) {
                     Collider<-1> col;
                     col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
-                    best = relax_target<-1, true>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj);
+                    best = relax_target<-1, true, COUNT>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col,
+                                                         &bj, &n_eval);
                 } else {
                     SL_RELAX(-1)
                 }
@@ -849,6 +858,12 @@ __global__ void sl_plan_kernel(SlDev a)
         l_cur = l_next;
         p1s = p2s;
         cur = nxt;
+    }
+    if constexpr (COUNT) {
+        // one add per wave
+        int c = n_eval;
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, MP_WAVE);
+        if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated, (unsigned long long)c);
     }
     if (done == n_s && n_s >= 2 && status == MP_SL_FOUND) {
         // the last layer's abort test
@@ -1497,9 +1512,34 @@ static int launch_check(const char *what)
     return MP_OK;
 }
 
+static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
+                          int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+                          double *best_cost, unsigned long long *n_evaluated, void *stream);
+
 extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
                           double *best_cost, void *stream)
+{
+    return sl_plan_launch(batch, params, cost_map, index_map, path_idx, status, layers_done, best_cost, nullptr,
+                          stream);
+}
+
+extern "C" int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
+                                  int32_t *status, int32_t *layers_done, double *best_cost,
+                                  uint64_t *n_evaluated, void *stream)
+{
+    if (!n_evaluated) { mp_set_error("mp_sl_plan_counted: null counter"); return MP_E_BADARG; }
+    if (batch && batch->n_l <= 16) {
+        mp_set_error("mp_sl_plan_counted: lattices of up to 16 lanes evaluate every edge; nothing to count");
+        return MP_E_UNSUPPORTED;
+    }
+    return sl_plan_launch(batch, params, nullptr, nullptr, path_idx, status, layers_done, best_cost,
+                          (unsigned long long *)n_evaluated, stream);
+}
+
+static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
+                          int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+                          double *best_cost, unsigned long long *n_evaluated, void *stream)
 {
     int rc = check_batch(batch, params);
     if (rc) return rc;
@@ -1520,10 +1560,11 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.best_cost = best_cost;
     a.edge_cost = nullptr;
     a.pair_cap = 0;
+    a.n_evaluated = n_evaluated;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
     // well (the two must agree bit for bit; used by the tests)
     const bool narrow_ok = mp_knob_sl_narrow() != 0;
-    if (n_l <= 16 && narrow_ok) {
+    if (n_l <= 16 && narrow_ok && !n_evaluated) {
         const int W = n_l <= 2 ? 2 : (n_l <= 4 ? 4 : (n_l <= 8 ? 8 : 16));
         const int threads = ((n_l * W + 63) / 64) * 64;
         int ncap = (7 * batch->ob_stride) / 2;
@@ -1573,7 +1614,10 @@ extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, 
     const bool maps = cost_map || index_map;
     const dim3 grid(batch->B), block(threads);
     hipStream_t st = (hipStream_t)stream;
-    if (shared_row && !maps) hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds, st, a);
+    if (n_evaluated) {
+        if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, false, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((sl_plan_kernel<false, false, true>), grid, block, lds, st, a);
+    } else if (shared_row && !maps) hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds, st, a);
     else if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, true>), grid, block, lds, st, a);
     else if (!maps) hipLaunchKernelGGL((sl_plan_kernel<false, false>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((sl_plan_kernel<false, true>), grid, block, lds, st, a);
@@ -1604,6 +1648,7 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     a.best_cost = nullptr;
     a.edge_cost = edge_cost;
     a.pair_cap = 0;
+    a.n_evaluated = nullptr;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fill_i32_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, status, batch->B,
                        MP_SL_FOUND);

@@ -118,6 +118,17 @@ def plan_scenes(scenes, dims, params, arena=None):
     return arena
 
 
+def plan_scenes_timed(scenes, dims, params, arena=None):
+    """mp_plan_scenes with a HIP event between its stages (measurement aid; blocks until
+    the chain has run).  Returns (arena, [(stage name, milliseconds), ...])."""
+    arena = arena or PlanArena(dims)
+    sb = SceneBatch(*[mb._p(scenes.get(n)) for n, _ in SceneBatch._fields_])
+    ms = (C.c_float * _lib.MP_PLAN_N_STAGES)()
+    check(lib().mp_plan_scenes_timed(C.byref(sb), C.byref(dims), C.byref(params), C.c_void_p(arena.base.data_ptr()),
+                                     arena.nbytes, mb._stream(), ms), "mp_plan_scenes_timed")
+    return arena, [(lib().mp_plan_stage_name(i).decode(), float(ms[i])) for i in range(_lib.MP_PLAN_N_STAGES)]
+
+
 def plan_scenes_static(scenes, dims, params, out=None):
     """Enqueues one mp_plan_scenes_static call: the same chain with every intermediate
     array in the library's own fixed device array, for callers that must not allocate

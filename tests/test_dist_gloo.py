@@ -66,6 +66,28 @@ def test_gather_world2(n_total):
         assert shape == (n_total, mdist.record_width(N_S, N_T))
 
 
+@pytest.mark.parametrize("flags,total,shards", [(["--total-scenarios", "37"], 37, [19, 18]),
+                                                (["--scenarios", "12"], 24, [12, 12]),
+                                                ([], 65536, [32768, 32768])])
+def test_bench_launches_its_own_ranks(flags, total, shards):
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks by
+    itself; --launch-check runs the sharding and the padded result exchange of the
+    benchmark over gloo on CPU tensors (no kernels), and rank 0 prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"] + flags,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["launch_check"] == "ok" and r["n_gpus"] == 2 and r["total_scenarios"] == total
+    assert r["shards"] == shards and r["backend"] == "gloo"
+    assert r["scaling"] == ("weak" if "--scenarios" in flags else "strong")
+
+
 def test_shard_range_covers_everything():
     for n, w in [(4096, 8), (65536, 8), (37, 2), (5, 8), (0, 4)]:
         spans = [mdist.shard_range(n, r, w) for r in range(w)]

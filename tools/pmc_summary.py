@@ -17,4 +17,4 @@ for d in sys.argv[1:]:
 for (k, c), v in sorted(acc.items()):
     if k.startswith("at::") or k.startswith("__amd"):
         continue
-    print("%-28s %-24s n=%-3d mean=%.6g" % (k[:28], c, len(v), sum(v) / len(v)))
+    print("%-40s %-24s n=%-3d mean=%.6g" % (k[:40], c, len(v), sum(v) / len(v)))
