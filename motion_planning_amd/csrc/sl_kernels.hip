@@ -254,6 +254,7 @@ struct PairStore {
     const int *layK;                // LDS: sample count code of every layer
     int *cntL;                      // LDS: pairs per layer
     unsigned short *offL;           // LDS: first pair of the layer in the store
+    unsigned *recL;                 // LDS (may be null): (pairs << 16 | first pair) of a stored layer, ~0u otherwise
     double *h0, *ol, *ds2;          // LDS: the store, cap entries each
 
     __device__ __forceinline__ LayerGeom geo(int s) const
@@ -368,8 +369,10 @@ struct PairStore {
                     if (off + c <= cap) {
                         offL[s] = (unsigned short)off;
                         cntL[s] = 0;
+                        if (recL) recL[s] = ((unsigned)c << 16) | (unsigned)off;
                     } else {
                         offL[s] = (s == s_begin) ? PAIRS_TOO_MANY : (unsigned short)cap;
+                        if (recL) recL[s] = ~0u;
                     }
                 }
                 carry += __shfl(incl, MP_WAVE - 1, MP_WAVE);
@@ -554,8 +557,9 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   lc[2][n_lp] double2 | layA layQ layW layP2 layMid [n_s] each | pairs[3][cap] (basis value,
 //   obstacle offset, squared arc-length gap) | red[2][8] redmax[8] | layK[n_s] int (K, bit 16: end
 //   point appended) | cntL[n_s] int (pairs per layer) | excL[n_s] int, first_ex[2] int (abort
-//   bookkeeping of layers without a barrier) | offL[n_s] u16 (first pair of the layer)
-//   | laySorted[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
+//   bookkeeping of layers without a barrier) | recL[n_s] u32 | offL[n_s] u16 (first pair of the layer)
+//   | laySorted[n_s] u8 (padded to 4) | locL[n_s] u8 (padded to 4: layers that need no exchange)
+//   | runL[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
 // SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
 // COUNT: measurement build that also adds the number of edges it priced to *a.n_evaluated
 template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
@@ -583,9 +587,12 @@ __global__ void sl_plan_kernel(SlDev a)
     int *cntL = layK + n_sm;
     int *excL = cntL + n_sm;      // per layer: waves whose targets all exceed the abort threshold
     int *first_ex = excL + n_sm;  // first layer every wave reported (2 ints, keeps what follows aligned)
-    unsigned short *offL = (unsigned short *)(first_ex + 2);
+    unsigned *recL = (unsigned *)(first_ex + 2); // per layer: pairs << 16 | first pair, ~0u = not in the store
+    unsigned short *offL = (unsigned short *)(recL + n_sm);
     unsigned char *laySorted = (unsigned char *)(offL + n_sm + (n_sm & 1));
-    unsigned char *idx8 = laySorted + ((n_sm + 3) & ~3);
+    unsigned char *locL = laySorted + ((n_sm + 3) & ~3); // 1: the layer is relaxed without looking at other lanes
+    unsigned char *runL = locL + ((n_sm + 3) & ~3); // the layer's sample count if it and its successor need no exchange, else 0
+    unsigned char *idx8 = runL + ((n_sm + 3) & ~3);
 
     if (n_s <= 0) { // nothing to plan for this scenario
         write_skipped(a, b, n_sm, n_l);
@@ -618,6 +625,8 @@ __global__ void sl_plan_kernel(SlDev a)
         layP2[s] = p2s;
         layMid[s] = lbase[(size_t)s * rstride + mid_l];
         laySorted[s] = 1;
+        locL[s] = 0;
+        runL[s] = 0;
         cntL[s] = 0;
         excL[s] = 0;
         if (g.K >= 0) {
@@ -664,7 +673,7 @@ __global__ void sl_plan_kernel(SlDev a)
     ps.ob_s = ob_s; ps.ob_l = ob_l;
     ps.has_ob = has_ob; ps.my_os = my_os; ps.my_ol = my_ol;
     ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
-    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL;
+    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL; ps.recL = recL;
     ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
     ps.count();
     __syncthreads();
@@ -723,6 +732,54 @@ __global__ void sl_plan_kernel(SlDev a)
         return gap2_min > 0.0 && w_inv_l > 0.0 && (top + 1e-12 * (g_max + top)) * w_inv_l < gap2_min;
     };
     for (int s = 0; s < n_s; ++s) {
+        if (local) {
+            // A run of layers that need nothing from the other lanes and whose successor
+            // does not either: this lane's straight edge (cost g_own, the value the closed
+            // form takes at dl = 0) against the layer's stored pairs, nothing else.  Layers
+            // that need more (a pair store to lay out again, another sample count, the
+            // layer in front of one that walks, the last layer) leave the run and take the
+            // general path below.
+            const int s_in = s;
+            unsigned rec_n = recL[s];
+            int k_n = runL[s];
+            const int k_run = __builtin_amdgcn_readfirstlane(g_K);
+            while (true) {
+                const unsigned rec = __builtin_amdgcn_readfirstlane(rec_n);
+                const int k = __builtin_amdgcn_readfirstlane(k_n);
+                if (k != k_run || k == 0 || rec == ~0u) break;
+                rec_n = recL[s + 1]; // k != 0: layer s + 1 exists
+                k_n = runL[s + 1];
+                const int ne = (int)(rec >> 16), off = (int)(rec & 0xffffu);
+                double best = 0.0;
+                if (is_target) {
+                    bool hit = false;
+                    for (int e = 0; e < ne; ++e) {
+                        // pair_hit at dl = 0: the sample sits on this lane
+                        const double d = l_cur - pair_ol[off + e];
+                        hit |= fma(d, d, pair_ds2[off + e]) < r2;
+                    }
+                    const double e = g_own + (hit ? pen : 0.0);
+                    best = e + cost_own;
+                    cost_own = best;
+                    if (MAPS) {
+                        const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
+                        if (a.cost_map) a.cost_map[o] = best;
+                        if (a.index_map) a.index_map[o] = tid;
+                    }
+                    if constexpr (COUNT) ++n_eval;
+                }
+                const bool all_above = __all(!is_target || best > abort_thr);
+                if (all_above && (tid & (MP_WAVE - 1)) == 0) {
+                    if (atomicAdd(&excL[s], 1) == nw - 1) atomicMin(first_ex, s);
+                }
+                ++s;
+            }
+            if (s != s_in) { // back to the general path at layer s (still one that needs no exchange)
+                done = s;
+                load_layer(s, cur);
+                p1s = layP2[s - 1];
+            }
+        }
         const int buf = s & 1;
         double m_prev = 0.0; // minimum accumulated cost over the previous layer
         if (s == 1) {
@@ -731,6 +788,19 @@ __global__ void sl_plan_kernel(SlDev a)
             for (int w = 1; w < nw; ++w) top0 = redmax[w] > top0 ? redmax[w] : top0;
             c_top = top0 < MP_INF ? (top0 + g_max + pen) * (1.0 + 1e-12) : MP_INF;
             local = false; // layer 1 still takes the walk (its minimum was reduced with layer 0's)
+            // which of the later layers need no exchange: the bound grows by the same amount
+            // per layer, so every layer's can be had now (read from layer 2's end on, behind
+            // the barrier that ends this layer)
+            for (int q = tid; q < n_s; q += nt) {
+                double c = c_top;
+                for (int t = 1; t < q; ++t) c = (c + g_max + pen) * (1.0 + 1e-12);
+                const bool loc = q >= 2 && is_local(c, layW[q]);
+                locL[q] = loc;
+                const int kq = layK[q];
+                const bool loc_next = q + 1 < n_s && q >= 1 &&
+                                      is_local((c + g_max + pen) * (1.0 + 1e-12), layW[q + 1]);
+                runL[q] = (loc && loc_next && kq >= 0) ? (unsigned char)(kq & 0xffff) : 0;
+            }
         }
         if (s > 0 && !local) {
             m_prev = red[buf * 8];
@@ -821,10 +891,10 @@ __global__ void sl_plan_kernel(SlDev a)
         }
         done = s + 1;
         if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
-        if (s >= 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer s + 1
-        const bool next_local = s >= 1 && s + 1 < n_s && is_local(c_top, nxt.w_inv);
+        if (s == 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer 2
+        const bool next_local = s >= 1 && s + 1 < n_s && (s == 1 ? is_local(c_top, nxt.w_inv) : locL[s + 1] != 0);
         if (is_target) {
-            idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
+            if (!local) idx8[(size_t)s * n_l + tid] = (unsigned char)bj; // a layer without exchange keeps every lane
             const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
             if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
@@ -912,7 +982,7 @@ __global__ void sl_plan_kernel(SlDev a)
                 int end_l = i;
                 pidx[n_s - 1] = end_l;
                 for (int q = n_s - 1; q >= 1; --q) {
-                    end_l = idx8[(size_t)q * n_l + end_l];
+                    if (!locL[q]) end_l = idx8[(size_t)q * n_l + end_l];
                     pidx[q - 1] = end_l;
                 }
             }
@@ -1009,7 +1079,7 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     ps.my_os = ps.has_ob ? ob_s[tid] : 0.0;
     ps.my_ol = ps.has_ob ? ob_l[tid] : 0.0;
     ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
-    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL;
+    ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL; ps.recL = nullptr;
     ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
     ps.count();
     __syncthreads();
@@ -1470,8 +1540,8 @@ extern void mp_set_error(const char *fmt, ...);
 static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
 {
     size_t d = (size_t)4 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 3 * (size_t)cap + 24;
-    size_t bytes = d * sizeof(double) + (3 * (size_t)n_s + 2) * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
-    bytes += (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
+    size_t bytes = d * sizeof(double) + (4 * (size_t)n_s + 2) * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
+    bytes += 3 * (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
 }
 
