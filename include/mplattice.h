@@ -25,6 +25,8 @@
  * mp_set_knob(): MP_SL_NARROW=0 (lattices of up to 16 lanes through the
  * thread-per-node kernel), MP_SL_PAIR_CAP=n (size of the kernels' LDS pair
  * store), MP_ST_REGIONS_ONCE=0 (per-layer scans in mp_st_regions),
+ * MP_ST_GENERIC=1 (mp_st_dp through the kernel that holds every relaxation path
+ * instead of the instance built for the batch's interval bound r_max),
  * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n (workgroup size of
  * mp_st_dp / mp_refline_tables / the front end of mp_plan_scenes; honoured only
  * when a multiple of 64 within 64..1024).

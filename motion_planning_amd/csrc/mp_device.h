@@ -16,6 +16,7 @@ int mp_knob_st_regions_once();
 int mp_knob_st_threads();
 int mp_knob_rl_threads();
 int mp_knob_fe_threads();
+int mp_knob_st_generic();
 #define MP_INF (__builtin_huge_val())
 
 // ---- wave-level reductions (64 lanes) ---------------------------------------

@@ -298,8 +298,12 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 //   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
 //   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim | hist[N] i32
 //   | cell tables dn[r_tab][N] cst[r_tab][N] | quiet[N] i32
-template <bool TABLES> // the cost / predecessor tables are written to global memory
-__global__ void st_dp_kernel(StDev a)
+// TABLES: the cost / predecessor tables are written to global memory.
+// RTK >= 0: an instance for batches with at most RTK blocked intervals per layer (layers
+// with fewer are padded with intervals that add exact zeros); it holds one relaxation path
+// instead of nine, needs fewer registers and runs at a higher occupancy.  RTK < 0: every path.
+template <bool TABLES, int RTK, int SPLITK>
+__device__ __forceinline__ void st_dp_body(StDev a)
 {
     if (!TABLES) a.cost = nullptr, a.pre = nullptr;
     extern __shared__ double smem[];
@@ -435,6 +439,13 @@ __global__ void st_dp_kernel(StDev a)
                 if (pre_g) pre_g[(size_t)i * N + j] = 0;
                 m_loc = best < m_loc ? best : m_loc;
             }
+        } else if (RTK >= 0) {
+            if constexpr (RTK >= 0) {
+                if (R <= RTK && R <= a.r_tab)
+                    m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                else
+                    m_loc = st_relax_layer<StCellLds>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+            }
         } else if (R <= a.r_tab && R <= 8) {
 #define ST_SPLIT_CASE(RT)                                                                                   \
     m_loc = N <= 48 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
@@ -506,6 +517,21 @@ __global__ void st_dp_kernel(StDev a)
         }
         a.path_len[b] = end_i + 1;
     }
+}
+
+template <bool TABLES>
+__global__ void st_dp_kernel(StDev a)
+{
+    st_dp_body<TABLES, -1, 0>(a);
+}
+
+#ifndef ST_WAVES_PER_EU
+#define ST_WAVES_PER_EU 6
+#endif
+template <int RTK, int SPLITK> // SPLITK lanes per cell: 4 on grids of up to 48 cells, else 8
+__attribute__((amdgpu_waves_per_eu(ST_WAVES_PER_EU, ST_WAVES_PER_EU))) __global__ void st_dp_r_kernel(StDev a)
+{
+    st_dp_body<false, RTK, SPLITK>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -794,8 +820,31 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double) +
                  (size_t)n_s_max * sizeof(int);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
-    if (cost || pre) hipLaunchKernelGGL(st_dp_kernel<true>, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(st_dp_kernel<false>, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
+    const dim3 grid(B), block(threads);
+    hipStream_t st = (hipStream_t)stream;
+    // batches with few intervals per layer (r_max is the caller's bound) take the instance
+    // built for that bound; MP_ST_GENERIC=1 keeps them on the kernel that holds every path
+    // large batches with few intervals per layer (r_max is the caller's bound) take the
+    // instance built for that bound and grid width class; MP_ST_GENERIC=1 keeps them on the
+    // kernel that holds every path
+    const int rk = (B >= 2048 && r_max <= 8 && r_max <= r_tab && mp_knob_st_generic() != 1)
+                       ? (r_max == 7 ? 8 : (r_max < 0 ? 0 : r_max)) : -1;
+#define ST_R_LAUNCH(RT)                                                                      \
+    if (n_s_max <= 48) hipLaunchKernelGGL((st_dp_r_kernel<RT, 4>), grid, block, lds, st, a); \
+    else hipLaunchKernelGGL((st_dp_r_kernel<RT, 8>), grid, block, lds, st, a)
+    if (cost || pre) hipLaunchKernelGGL(st_dp_kernel<true>, grid, block, lds, st, a);
+    else switch (rk) {
+        case 0: ST_R_LAUNCH(0); break;
+        case 1: ST_R_LAUNCH(1); break;
+        case 2: ST_R_LAUNCH(2); break;
+        case 3: ST_R_LAUNCH(3); break;
+        case 4: ST_R_LAUNCH(4); break;
+        case 5: ST_R_LAUNCH(5); break;
+        case 6: ST_R_LAUNCH(6); break;
+        case 8: ST_R_LAUNCH(8); break;
+        default: hipLaunchKernelGGL(st_dp_kernel<false>, grid, block, lds, st, a); break;
+    }
+#undef ST_R_LAUNCH
     return st_launch_check("mp_st_dp");
 }
 
