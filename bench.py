@@ -726,10 +726,10 @@ def bench_lattice(args, job):
         h2d = (hsecs, loop.bytes)
 
     # edges the fused kernel really prices (counting instance, outside the timed region)
-    edges_eval = None
+    edges_eval = edges_serial = None
     if rank == 0 and not args.early_exit:
         cnt_out = mb.SLPlanOut(B, N_S, N_L, want_maps=False)
-        _, edges_eval = mb.sl_plan_counted(sb, prm, cnt_out)
+        _, edges_eval, edges_serial = mb.sl_plan_counted(sb, prm, cnt_out)
         assert torch.equal(cnt_out.path_idx, out.path_idx) and torch.equal(cnt_out.status, out.status)
 
     if rank != 0:
@@ -777,6 +777,7 @@ def bench_lattice(args, job):
                "edge_costs": "not materialised", "workgroups_per_cu": 8, "waves_per_simd": 4,
                "us_per_layer_per_launch": 1e3 * sl_ms / N_S,
                "edges_evaluated_per_launch": edges_eval,
+               "lane_efficiency": edges_eval / (64.0 * edges_serial) if edges_serial else None,
                "edges_evaluated_per_sec": edges_eval / (sl_ms * 1e-3) if edges_eval else None,
                "evaluated_fraction_of_lattice": edges_eval / edges_nominal if edges_eval else None,
                "lattice_edges_nominal_per_launch": edges_nominal,

@@ -124,8 +124,10 @@ int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cos
 /* Measurement aid, no counterpart in the reference: mp_sl_plan (maps not
  * written) by an instance of the same kernel that also counts the lattice edges
  * it actually prices -- exact pruning skips most of the n_l + (n_s-1)*n_l^2 edges
- * of a plan -- and ADDS that count, summed over the batch, to *n_evaluated (one
- * device uint64 the caller zeroes).  Lattices of more than 16 lanes only (the
+ * of a plan -- and ADDS that count, summed over the batch, to n_evaluated[0];
+ * n_evaluated[1] receives the edges priced one after the other (the busiest lane
+ * of every wave, layer by layer), which is what the kernel's time follows
+ * (n_evaluated: two device uint64 the caller zeroes).  Lattices of more than 16 lanes only (the
  * narrow kernel prices every edge).  Results are identical to mp_sl_plan's. */
 int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
                        int32_t *status, int32_t *layers_done, double *best_cost, uint64_t *n_evaluated,

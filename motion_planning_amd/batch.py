@@ -114,16 +114,18 @@ def sl_plan(batch, params=None, out=None, want_maps=True):
 
 def sl_plan_counted(batch, params=None, out=None):
     """mp_sl_plan through the counting instance of the fused kernel (measurement aid):
-    returns (out, edges the kernel priced over the whole batch).  Reads the counter back,
-    so it synchronises."""
+    returns (out, edges the kernel priced over the whole batch, edges priced one after the
+    other: the busiest lane of every wave, layer by layer).  Reads the counters back, so it
+    synchronises."""
     params = params or sl_params(n_l=batch.n_l)
     out = out or SLPlanOut(batch.B, batch.n_s, batch.n_l, False)
-    n_eval = torch.zeros(1, dtype=torch.int64, device=batch.s_layers.device)
+    n_eval = torch.zeros(2, dtype=torch.int64, device=batch.s_layers.device)
     cs = batch.c_struct()
     check(lib().mp_sl_plan_counted(C.byref(cs), C.byref(params), _p(out.path_idx), _p(out.status),
                                    _p(out.layers_done), _p(out.best_cost), _p(n_eval), _stream()),
           "mp_sl_plan_counted")
-    return out, int(n_eval.item())
+    n_eval = n_eval.cpu()
+    return out, int(n_eval[0]), int(n_eval[1])
 
 
 def sl_edge_cost(batch, params=None):

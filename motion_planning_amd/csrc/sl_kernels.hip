@@ -491,6 +491,16 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
         bj = j;
         if (w_inv > 0.0) w2 = window(best);
     };
+    // A candidate inside the window is priced only if its own accumulated cost leaves room:
+    // its total is at least cp + cSH*dl^2 (the window's argument with cp in place of the
+    // layer minimum), so where that already exceeds `best` the closed form and the collision
+    // test are skipped.  On a layer whose costs rise steeply away from the ego (the first
+    // ones) most of the window falls to this test.
+    auto cannot_win = [&](double dl2, double cp) {
+        double gap = best - cp;
+        gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
+        return w_inv > 0.0 && dl2 > gap * w_inv;
+    };
     // outwards on both sides in turn, so that a free edge close by is found (and shrinks
     // the window) before the far side of a blocked stretch has been walked
     int jd = j0 - 1, ju = j0 + 1;
@@ -501,7 +511,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 jd = (sorted && dl > 0.0) ? -1 : jd - 1; // sorted: sources further down are further away
             } else {
-                consider(jd, lc.x, lc.y, dl);
+                if (!cannot_win(dl * dl, lc.y)) consider(jd, lc.x, lc.y, dl);
                 --jd;
             }
         }
@@ -511,7 +521,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 ju = (sorted && dl < 0.0) ? n_src : ju + 1;
             } else {
-                consider(ju, lc.x, lc.y, dl);
+                if (!cannot_win(dl * dl, lc.y)) consider(ju, lc.x, lc.y, dl);
                 ++ju;
             }
         }
@@ -565,7 +575,7 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
 __global__ void sl_plan_kernel(SlDev a)
 {
-    int n_eval = 0;
+    int n_eval = 0, n_eval_seen = 0;
     if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -768,6 +778,10 @@ __global__ void sl_plan_kernel(SlDev a)
                     }
                     if constexpr (COUNT) ++n_eval;
                 }
+                if constexpr (COUNT) {
+                    n_eval_seen = n_eval;
+                    if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, 1ull);
+                }
                 const bool all_above = __all(!is_target || best > abort_thr);
                 if (all_above && (tid & (MP_WAVE - 1)) == 0) {
                     if (atomicAdd(&excL[s], 1) == nw - 1) atomicMin(first_ex, s);
@@ -888,6 +902,14 @@ __global__ void sl_plan_kernel(SlDev a)
                 break;
             }
 #undef SL_RELAX
+        }
+        if constexpr (COUNT) {
+            // second counter: edges priced one after the other, i.e. the busiest lane of
+            // every wave, layer by layer (what the wave's time follows)
+            int c = n_eval - n_eval_seen;
+            n_eval_seen = n_eval;
+            for (int m = 32; m >= 1; m >>= 1) c = max(c, __shfl_xor(c, m, MP_WAVE));
+            if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, (unsigned long long)c);
         }
         done = s + 1;
         if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields

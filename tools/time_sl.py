@@ -22,6 +22,8 @@ def main():
     sc = make_scenarios(0, B)
     if os.environ.get('SL_NO_OB'):   # the same lattice without obstacles: the DP's fixed cost per layer
         sc["n_ob"] = sc["n_ob"] * 0
+    if os.environ.get('SL_OB_SCALE'):   # shrink the collision radius: fewer pairs, fewer blocked edges
+        sc["ob_dist"] = sc["ob_dist"] * float(os.environ['SL_OB_SCALE'])
     n_layers = None
     if os.environ.get('SL_LAYERS'):   # only the first k layers of every scenario: where the time goes
         import numpy as np
