@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 120
+#define MP_VERSION 121
 
 /* host-side return codes */
 #define MP_OK 0
@@ -139,6 +139,20 @@ int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int
  * MP_SL_FOUND means "ok"). */
 int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *params, double *edge_cost,
                     int32_t *status, void *stream);
+
+/* PathPlanner.cal_cost + get_path (path_planner.py:104-155) for a lattice whose
+ * nodes carry their own arc length: the reference reads s_map[s][l] per node
+ * (:106,109), so a layer need not sit at one s (SLMap never builds such a lattice,
+ * sl_map.py:69-78, but a caller may fill s_map by hand).  s_map, l_map
+ * [B][n_s][n_l]; the rest as in mp_sl_batch; n_layers may be NULL.  One thread
+ * per edge, every sample and every obstacle visited, no limit of 128 samples per
+ * edge (up to 2^20; more reports MP_SL_E_CAPACITY): the general, slow companion
+ * of mp_sl_edge_cost, with the same edge_cost layout and status; follow it with
+ * mp_sl_dp.  Any n_l, n_s; B <= 65535. */
+int mp_sl_edge_cost_nodes(int32_t B, int32_t n_s, int32_t n_l, const double *s_map, const double *l_map,
+                          const double *ego_sl, const double *ob_s, const double *ob_l, int32_t ob_stride,
+                          const int32_t *n_ob, const double *ob_dist, const int32_t *n_layers,
+                          const mp_sl_params *params, double *edge_cost, int32_t *status, void *stream);
 
 /* Replaces PathPlanner.find_path/find_path_point (path_planner.py:66-101) over
  * a materialised edge-cost tensor: layer-wise min-relaxation with first-minimum

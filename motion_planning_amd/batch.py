@@ -141,6 +141,32 @@ def sl_edge_cost(batch, params=None):
     return edge, status
 
 
+def sl_edge_cost_nodes(s_map, l_map, ego_sl, ob_s, ob_l, n_ob, ob_dist, params=None, n_layers=None):
+    """Edge costs of lattices whose nodes carry their own arc length (the reference reads
+    s_map[s][l] per node, path_planner.py:104-123), any number of samples per edge.
+
+    s_map / l_map [B, n_s, n_l]; ego_sl [B, 2]; ob_s / ob_l [B, ob_stride]; n_ob, ob_dist [B].
+    Returns (edge_cost [B, n_s, n_l(to), n_l(from)], status [B]) as sl_edge_cost does."""
+    s_map, l_map, ego_sl = to_dev(s_map), to_dev(l_map), to_dev(ego_sl)
+    B, n_s, n_l = s_map.shape
+    assert l_map.shape == (B, n_s, n_l) and ego_sl.shape == (B, 2)
+    ob_s, ob_l = to_dev(ob_s).reshape(B, -1), to_dev(ob_l).reshape(B, -1)
+    assert ob_s.shape == ob_l.shape
+    ob_stride = ob_s.shape[1]
+    n_ob, ob_dist = to_dev(n_ob, torch.int32), to_dev(ob_dist)
+    assert n_ob.shape == (B,) and ob_dist.shape == (B,)
+    assert int(n_ob.max()) <= ob_stride
+    n_layers = to_dev(n_layers, torch.int32) if n_layers is not None else None
+    params = params or sl_params(n_l=n_l)
+    edge = torch.empty((B, n_s, n_l, n_l), dtype=torch.float64, device=s_map.device)
+    status = torch.empty(B, dtype=torch.int32, device=s_map.device)
+    check(lib().mp_sl_edge_cost_nodes(B, n_s, n_l, _p(s_map), _p(l_map), _p(ego_sl),
+                                      _p(ob_s if ob_stride else None), _p(ob_l if ob_stride else None), ob_stride,
+                                      _p(n_ob), _p(ob_dist), _p(n_layers), C.byref(params), _p(edge), _p(status),
+                                      _stream()), "mp_sl_edge_cost_nodes")
+    return edge, status
+
+
 def sl_dp(edge_cost, params, out=None, n_layers=None):
     """Layer-wise min-relaxation over materialised edge costs (path_planner.py:66-101)."""
     B, n_s, n_l, _ = edge_cost.shape

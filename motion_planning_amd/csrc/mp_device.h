@@ -205,3 +205,52 @@ __device__ __forceinline__ double arange_value(int k, int n, double t_st, double
     if (k == 1) return __dadd_rn(t_st, dt);
     return __dadd_rn(t_st, __dmul_rn((double)k, delta));
 }
+
+// ---- quintic pieces (Model/curve.py) -----------------------------------------
+
+// Model/curve.py:130-157 QuinticPoly coefficients.
+__device__ __forceinline__ void quintic_coef(double xs, double vxs, double axs, double xe, double vxe, double axe, double T,
+                             double *a)
+{
+    a[0] = xs;
+    a[1] = vxs;
+    a[2] = axs / 2.0;
+    a[3] = 1.0 * (20 * xe - 20 * xs - (8 * vxe + 12 * vxs) * T - (3 * axs - axe) * T * T) / (2 * T * T * T);
+    a[4] = 1.0 * (30 * xs - 30 * xe + (14 * vxe + 16 * vxs) * T + (3 * axs - 2 * axe) * T * T) /
+           (2 * T * T * T * T);
+    a[5] = 1.0 * (12 * xe - 12 * xs - (6 * vxe + 6 * vxs) * T - (axs - axe) * T * T) /
+           (2 * T * T * T * T * T);
+}
+
+// Model/curve.py:159-173 calc_point (power form; powers by repeated multiply).
+__device__ __forceinline__ double quintic_eval(const double *a, double t, int order)
+{
+    const double t2 = t * t, t3 = t2 * t;
+    if (order == 0) return a[0] + a[1] * t + a[2] * t2 + a[3] * t3 + a[4] * (t2 * t2) + a[5] * (t2 * t3);
+    if (order == 1) return a[1] + 2 * a[2] * t + 3 * a[3] * t2 + 4 * a[4] * t3 + 5 * a[5] * (t2 * t2);
+    if (order == 2) return 2 * a[2] + 6 * a[3] * t + 12 * a[4] * t2 + 20 * a[5] * t3;
+    return 6 * a[3] + 24 * a[4] * t + 60 * a[5] * t2;
+}
+
+// np.sum (pairwise order, n <= 128) over generated elements f(i).
+template <class F>
+__device__ __forceinline__ double np_sum_gen(int n, F f)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += f(i);
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f(j);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += f(i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += f(i);
+    return res;
+}
+

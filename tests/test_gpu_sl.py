@@ -1,5 +1,7 @@
 """SL path DP on the GPU (through the C ABI) against the reference's golden
 outputs and against the CPU oracle on seeded random lattices."""
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import pytest
 
@@ -310,6 +312,69 @@ def test_sl_empty_edge_and_capacity_status():
     assert r["status"] == _lib.MP_SL_FOUND                  # no obstacles: empty edge costs 0
 
 
+def gpu_sl_nodes(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, n_layers=None):
+    """Per-node edge kernel + DP kernel; returns (list of result dicts, edge tensor, edge status)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    ob_s, ob_l, n_ob = pad_obstacles(obs)
+    prm = mb.sl_params(early_exit=early_exit, mid_l=mid_l)
+    edge, st = mb.sl_edge_cost_nodes(s_map, l_map, ego, ob_s, ob_l, n_ob, ob_dist, prm, n_layers=n_layers)
+    out = mb.sl_dp(edge, prm, n_layers=n_layers)
+    torch.cuda.synchronize()
+    res = [dict(found=int(out.status[b]) == 1, status=int(out.status[b]), cost_map=out.cost_map[b].cpu().numpy(),
+                index_map=out.index_map[b].cpu().numpy(), path_idx=out.path_idx[b].cpu().numpy(),
+                layers_done=int(out.layers_done[b])) for b in range(len(s_map))]
+    return res, edge.cpu().numpy(), st.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(6, 5, 5, 8.0, 6), (4, 6, 12, 3.0, 15), (2, 3, 40, 20.0, 30), (3, 3, 5, 90.0, 8)],
+                         ids=lambda s: "B%d_%dx%d_gap%g" % s[:4])
+def test_sl_per_node_lattice_vs_oracle(oracle, shape):
+    """Every node at its own arc length (the reference reads s_map[s][l] per node,
+    path_planner.py:106-109); the widest gaps give edges of more than 128 samples."""
+    B, n_s, n_l, gap, n_ob = shape
+    rng = np.random.default_rng(4000 + n_s * n_l)
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, gap, n_ob, 0.3, 0.8)
+    s_map = s_map + rng.uniform(-0.2 * gap, 0.2 * gap, s_map.shape)
+    l_map = l_map + rng.uniform(-0.05, 0.05, l_map.shape)
+    mid_l = int((n_l - 1) / 2)
+    res, edge, st = gpu_sl_nodes(s_map, l_map, mid_l, ego, obs, ob_dist)
+    assert (st == 1).all()
+    for b in range(B):
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b], no_early_exit=True,
+                                  want_edges=True)
+        assert_costs(edge[b, 0, :, 0], ref["edge_cost"][0, :, 0])
+        assert_costs(edge[b, 1:], ref["edge_cost"][1:])
+        assert np.isnan(edge[b, 0, :, 1:]).all()
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b])
+        assert_sl_parity(res[b], ref)
+
+
+def test_sl_per_node_kernel_equals_layer_kernel_on_layered_lattices():
+    rng = np.random.default_rng(5)
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, 5, 6, 9, 6.0, 12, 0.3, 0.8, jitter=True)
+    n_layers = np.array([6, 3, 1, 6, 4], np.int32)
+    res, edge, st = gpu_sl_nodes(s_map, l_map, 4, ego, obs, ob_dist, n_layers=n_layers)
+    res_l, edge_l = gpu_sl(s_map, l_map, 4, ego, obs, ob_dist, split=True, n_layers=n_layers)
+    for b in range(5):
+        d = n_layers[b]
+        assert_costs(edge[b, 0, :, 0], edge_l[b, 0, :, 0])
+        assert_costs(edge[b, 1:d], edge_l[b, 1:d])
+        assert np.isnan(edge[b, d:]).all()
+        assert res[b]["status"] == res_l[b]["status"] and res[b]["layers_done"] == res_l[b]["layers_done"]
+        assert np.array_equal(res[b]["index_map"], res_l[b]["index_map"])
+
+
+def test_sl_per_node_empty_edge_status():
+    from motion_planning_amd import _lib
+    s_map = np.array([[[8.0, 8.0, 8.0], [16.0, 8.3, 16.0]]])     # node (1,1) 0.3 m behind layer 0: no sample
+    l_map = np.broadcast_to(np.linspace(-1, 1, 3), (1, 2, 3)).copy()
+    _, edge, st = gpu_sl_nodes(s_map, l_map, 1, np.zeros((1, 2)), [np.array([[3.0, 0.0]])], np.array([0.5]))
+    assert st[0] == _lib.MP_SL_E_EMPTY_EDGE and np.isnan(edge[0, 1, 1]).all() and np.isfinite(edge[0, 1, 0]).all()
+    _, edge, st = gpu_sl_nodes(s_map, l_map, 1, np.zeros((1, 2)), [np.zeros((0, 2))], np.array([0.5]))
+    assert st[0] == _lib.MP_SL_FOUND and (edge[0, 1, 1] == 0).all()     # no obstacles: the empty edge costs 0
+
+
 @pytest.mark.parametrize("n_l", [5, 24])
 def test_sl_layers_out_of_order(oracle, n_l):
     """A layer placed behind its predecessor ends the plan there (an edge without samples
@@ -502,12 +567,27 @@ def test_sl_cfg3_subset_vs_oracle_and_properties(oracle):
         for b in np.flatnonzero(status == 0)[:200]:
             assert (path[b] == -1).all()
             assert cm[b, done[b] - 1].min() > 1e5 if early else True
-        # a handful of full-size scenarios against the oracle
-        for b in list(found[:2]) + list(np.flatnonzero(status == 0)[:2]):
+        # the instance that writes no maps (the one the benchmark times) decides the same plan
+        lean = mb.sl_plan(sb, mb.sl_params(early_exit=early, n_l=128), want_maps=False)
+        torch.cuda.synchronize()
+        assert lean.cost_map is None and lean.index_map is None
+        assert torch.equal(lean.path_idx, out.path_idx) and torch.equal(lean.status, out.status)
+        assert torch.equal(lean.layers_done, out.layers_done)
+        assert np.array_equal(lean.best_cost.cpu().numpy(), out.best_cost.cpu().numpy(), equal_nan=True)
+        # full-size scenarios against the oracle, found and not found alike
+        n_each = 32 if early else 8
+        sample = list(found[:n_each]) + list(np.flatnonzero(status == 0)[:n_each])
+        assert len(sample) == 2 * n_each
+
+        def reference(b):
             s_map = np.repeat(s_layers[b][:, None], 128, axis=1)
             l_map = np.broadcast_to(l_row[b], (64, 128))
-            ref = oracle.sl_find_path(s_map, l_map, 63, ego[b], np.stack([ob_s[b], ob_l[b]], 1), ob_dist[b],
-                                      no_early_exit=not early)
+            return oracle.sl_find_path(s_map, l_map, 63, ego[b], np.stack([ob_s[b], ob_l[b]], 1), ob_dist[b],
+                                       no_early_exit=not early)
+
+        with ThreadPoolExecutor(8) as pool:      # the oracle is a C call that releases the interpreter lock
+            refs = list(pool.map(reference, sample))
+        for b, ref in zip(sample, refs):
             got = dict(found=status[b] == 1, cost_map=cm[b], index_map=idx[b], path_idx=path[b],
                        layers_done=done[b])
             assert_sl_parity(got, ref)
