@@ -55,6 +55,12 @@ extern "C" {
                                    the reference raises ValueError (min of empty) */
 #define MP_SL_E_CAPACITY (-3) /* more than MP_SL_K_CAP samples on one edge        */
 #define MP_SL_SKIPPED (-4)    /* the scenario's layer count is 0: nothing was planned */
+/* Samples per edge the layer kernels (mp_sl_plan, mp_sl_edge_cost) hold: 64 m
+ * between layers at the reference's d_s = 0.5, where SLMap's own lattices stop
+ * at 12 m (sl_map.py:69-78).  A scenario with a longer edge gets
+ * MP_SL_E_CAPACITY from them and nothing else of it is written;
+ * mp_sl_edge_cost_nodes + mp_sl_dp price such a lattice (up to 2^20 samples an
+ * edge), and the Python PathPlanner falls to that pair by itself. */
 #define MP_SL_K_CAP 128
 
 /* per-scenario status written by mp_st_regions */
