@@ -16,6 +16,7 @@
 
 struct StDev {
     int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
+    int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -111,10 +112,26 @@ struct StCellLds {
     }
 };
 
+// LDS rows of the DP.  What the edge loop reads together sits together, so one 16-byte
+// read serves two tables: fs[d] = (front[d], speed[d]) and, per cell of a cost row,
+// (cost, history word).  The history word of predecessor p of the current layer packs
+// 8*(pp - 2p) in the low half and 8*(3pp - ppp - 3p) in the high half (on layer 2, whose
+// jerk has no third predecessor, 8*(pp - 2p) again): byte offsets into the acceleration
+// and jerk tables, looked up once per layer instead of two dependent reads per edge.
+// Lanes per cell of the split relaxation.  Pruning makes the walks short, so in a large
+// batch (throughput) the cost of a pass over the cells counts as much as the balance of the
+// lanes: grids of up to 128 cells give a cell 4 lanes (two passes of 64 cells instead of four
+// of 32 on a 97-cell grid), wider ones 8.  A small batch (latency) keeps 8 lanes from 49 cells on.
+static inline int st_lanes_per_cell(int B, int n_s_max) { return n_s_max <= (B > 512 ? 128 : 48) ? 4 : 8; }
+
 struct StSh {
-    double *cost_prev, *cost_cur, *front, *speed, *acc, *jerk2, *jerk3, *down, *up;
+    double *ch_prev, *ch_cur, *fs, *acc, *jerk2, *jerk3, *down, *up;
     short *pre16;
-    int *hist; // [N], per predecessor p of the current layer: (pp - 2p) in the low half, (3pp - ppp - 3p) in the high half
+    __device__ __forceinline__ double &cost_prev(int p) const { return ch_prev[2 * p]; }
+    __device__ __forceinline__ double &cost_cur(int j) const { return ch_cur[2 * j]; }
+    __device__ __forceinline__ int &hist_prev(int p) const { return *(int *)(ch_prev + 2 * p + 1); }
+    __device__ __forceinline__ double &front(int d) const { return fs[2 * d]; }
+    __device__ __forceinline__ double &speed(int d) const { return fs[2 * d + 1]; }
 };
 
 // All cells of time layer i >= 2 owned by this thread.
@@ -144,8 +161,8 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
         int bp = -1;
         for (int p = j; p >= 0; --p) {
             const int d = j - p;
-            const double cp = sh.cost_prev[p];
-            const double base = __dadd_rn(cell.ob(s, sh.front[d]), sh.speed[d]);
+            const double cp = sh.cost_prev(p);
+            const double base = __dadd_rn(cell.ob(s, sh.front(d)), sh.speed(d));
             if (bp >= 0) {
                 if (cell.monotone && d >= d_lim && __dadd_rn(base, m_prev) > best) break;
                 if (__dadd_rn(base, cp) > best) continue;
@@ -162,7 +179,7 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
             const double c = __dadd_rn(tot, cp);
             if (bp < 0 || c <= best) { best = c; bp = p; } // lower index wins ties
         }
-        sh.cost_cur[j] = best;
+        sh.cost_cur(j) = best;
         sh.pre16[(size_t)i * N + j] = (short)bp;
         if (cost_g) cost_g[(size_t)i * N + j] = best;
         if (pre_g) pre_g[(size_t)i * N + j] = bp;
@@ -171,32 +188,52 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
     return m_loc;
 }
 
-// Per-cell interval tables in LDS, [interval][cell].
+// Per-cell interval records in LDS, one per cell: r_tab pairs (dn, cst); then two ints: 16
+// times the smallest predecessor distance at which any interval takes the front formula,
+// and a word that is non-zero when the cell's obstacle cost is not monotone in the edge
+// speed; then, as u16 x 8, 16 times that distance for each interval (0xffff: never).
+// Without interval slots (r_tab = 0) a record is the two ints alone.
 struct StTab {
-    double *dn, *cst; // [r_tab][N]
-    int *quiet;       // [N]: below this predecessor distance none of the cell's intervals takes the front formula
+    double *rec;
+    int stride; // doubles per record
+    int r_tab;
+    __device__ __forceinline__ double *cell(int j) const { return rec + (size_t)j * stride; }
+    __device__ __forceinline__ int *quiet(int j) const { return (int *)(cell(j) + 2 * r_tab); }
 };
+__host__ __device__ __forceinline__ int st_rec_stride(int r_tab) { return r_tab > 0 ? 2 * r_tab + 4 : 1; }
 
-// Bytes of dynamic LDS in front of the cell tables (see st_dp_kernel).
+// Bytes of dynamic LDS in front of the cell records (see st_dp_kernel).
 __host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t)
 {
-    size_t b = ((size_t)12 * N + 2 * r_max + n_t + 8) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
-               (2 + (size_t)N) * sizeof(int);
+    size_t b = ((size_t)14 * N + 2 * r_max + n_t + 8) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
+               2 * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
+__host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
+{
+    return (size_t)N * st_rec_stride(r_tab) * sizeof(double);
+}
 
-// All cells of time layer i >= 2, ST_SPLIT lanes per cell (8 below; 4 on small grids).
+// All cells of time layer i >= 2, ST_SPLIT lanes per cell.
 //
 // A thread per cell leaves most lanes idle (cell j has j+1 predecessors and a
-// wave runs as long as its longest cell).  Here the lanes of a wave hold 8
-// neighbouring cells, and the 8 lanes of a cell take predecessors
-// p = j-r, j-r-8, ... (r = lane within the cell): the waves of a workgroup then
+// wave runs as long as its longest cell).  Here the lanes of a wave hold
+// neighbouring cells, and the ST_SPLIT lanes of a cell take predecessors
+// p = j-r, j-r-ST_SPLIT, ... (r = lane within the cell): the waves of a workgroup then
 // carry almost equal work, and neighbouring lanes read neighbouring table
 // entries.  Each lane keeps its own first minimum (walking towards lower p with
-// "<="), the 8 partial results are merged on (cost, p), so the lowest p among
+// "<="), the partial results are merged on (cost, p), so the lowest p among
 // equal costs wins exactly as in the reference's list.index(min(...))
 // (speed_planner.py:102-111).  The monotone bound of st_relax_layer ends a
 // lane's walk early; what it skips is strictly worse than that lane's best.
+//
+// Whether an interval ahead of a cell takes the front formula, s >= dn - front[d], can only
+// turn from false to true as the predecessor distance d grows (front[] does not decrease and
+// rounding is monotone), so the classification of a layer finds, with that very test, the
+// first distance at which it holds; the edge loop then compares integers.  Pruning makes the
+// walks short (three or four steps per lane on a 97-cell grid), so what a pass over the
+// cells costs outside the walk matters as much as the walk: a cell's intervals, fire
+// distances and flags are one record, read with constant offsets from one address.
 template <int RT, int ST_SPLIT>
 __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb, int i,
                                                        int n_s, int N, int R, int d_lim, double m_prev,
@@ -205,32 +242,41 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     const int tid = threadIdx.x, nt = blockDim.x;
     const double ds = a.ds;
     const int n1 = n_s - 1;
-    // (tb.quiet[] was set to "never" before the barrier in front of this call)
-    const double front_step = sh.front[n_s > 1 ? 1 : 0];
+    // (every record's quiet word and flag word were reset before the barrier in front of this call)
+    const double front_step = sh.front(n_s > 1 ? 1 : 0);
     const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
-    for (int q = tid; q < n_s * R; q += nt) {
+    for (int q = tid; q < n_s * RT; q += nt) {
         const int k = q / n_s, j = q - k * n_s;
-        const double s = __dmul_rn((double)j, ds);
-        double dnk, ck;
-        StCell<1>::classify(s, sh.down[k], sh.up[k], &dnk, &ck);
-        tb.dn[k * N + j] = dnk;
-        tb.cst[k * N + j] = ck;
-        if (dnk != MP_INF) {
-            // A distance below which this interval cannot take the front formula: the test
-            // s >= dn - front[d] can only turn from false to true as d grows (front[] does not
-            // decrease), so it is enough that it fails at the distance just below.  The
-            // estimate only has to be close; the loop makes it safe.
-            int dq = n_s;
-            if (front_step > 0.0) {
-                const double g = (dnk - s) * inv_front_step;
-                dq = g < (double)n_s ? (g > 0.0 ? (int)g : 0) : n_s;
+        double *rec = tb.cell(j);
+        double dnk = MP_INF, ck = 0.0; // slots beyond the layer's intervals never fire and add exact zeros
+        unsigned e_fire = 0xffffu;
+        if (k < R) {
+            const double s = __dmul_rn((double)j, ds);
+            StCell<1>::classify(s, sh.down[k], sh.up[k], &dnk, &ck);
+            if (dnk != MP_INF) {
+                // the estimate only has to be close; the two loops make it exact
+                int dq = n_s;
+                if (front_step > 0.0) {
+                    const double g = (dnk - s) * inv_front_step;
+                    dq = g < (double)n_s ? (g > 0.0 ? (int)g : 0) : n_s;
+                }
+                while (dq > 0 && s >= __dsub_rn(dnk, sh.front(dq - 1))) --dq;
+                while (dq < n_s && !(s >= __dsub_rn(dnk, sh.front(dq)))) ++dq;
+                e_fire = (unsigned)dq * 16u;
+                atomicMin(tb.quiet(j), (int)e_fire);
+                // an interval whose end precedes its start could trade a large "behind"
+                // constant for a small front term
+                if (ck != 0.0) atomicOr(tb.quiet(j) + 1, 1);
             }
-            while (dq > 0 && s >= __dsub_rn(dnk, sh.front[dq - 1])) --dq;
-            atomicMin(&tb.quiet[j], dq);
         }
+        rec[2 * k] = dnk;
+        rec[2 * k + 1] = ck;
+        ((unsigned short *)(rec + 2 * tb.r_tab + 1))[k] = (unsigned short)e_fire;
     }
     __syncthreads();
     const int r = tid & (ST_SPLIT - 1), g = tid / ST_SPLIT, G = nt / ST_SPLIT;
+    const double *jerk_row = (i == 2) ? sh.jerk2 + n1 : sh.jerk3 + 2 * n1;
+    const int e_lim = d_lim * 16;
     double m_loc = MP_INF;
     // cells are taken from the far end downwards: whatever is left over for the last,
     // partly filled pass are then the cells next to s = 0, which have the fewest
@@ -245,46 +291,65 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
         double best = MP_INF;
         int bp = 0x7fffffff;
         if (live) {
-            StCell<RT> cell;
-            cell.monotone = true;
+            const double *rec = tb.cell(j);
+            double dn[RT > 0 ? RT : 1], cst[RT > 0 ? RT : 1];
+            unsigned fire[(RT + 1) / 2 > 0 ? (RT + 1) / 2 : 1];
 #pragma unroll
             for (int k = 0; k < RT; ++k) {
-                if (k < R) {
-                    cell.dn[k] = tb.dn[k * N + j];
-                    cell.cst[k] = tb.cst[k * N + j];
-                    if (cell.dn[k] != MP_INF && cell.cst[k] != 0.0) cell.monotone = false;
-                } else { cell.dn[k] = MP_INF; cell.cst[k] = 0.0; }
+                const double2 v = ((const double2 *)rec)[k];
+                dn[k] = v.x;
+                cst[k] = v.y;
             }
+#pragma unroll
+            for (int k = 0; k < (RT + 1) / 2; ++k) fire[k] = ((const unsigned *)(rec + 2 * tb.r_tab + 1))[k];
+            const int2 qf = *(const int2 *)(rec + 2 * tb.r_tab);
+            const int e_quiet = RT > 0 ? qf.x : 0;
+            const int e_brk = (RT == 0 || qf.y == 0) ? e_lim : 0x7fffffff;
             const double s = __dmul_rn((double)j, ds);
             // what the obstacle sum comes to while no interval takes the front formula: the
             // same additions in the same order with every term at its constant
             double ob_quiet = 0.0;
 #pragma unroll
-            for (int k = 0; k < RT; ++k) ob_quiet = (k == 0) ? cell.cst[0] : __dadd_rn(ob_quiet, cell.cst[k]);
-            const int d_quiet = RT > 0 ? tb.quiet[j] : 0;
-            for (int p = j - r; p >= 0; p -= ST_SPLIT) {
-                const int d = j - p;
+            for (int k = 0; k < RT; ++k) ob_quiet = (k == 0) ? cst[0] : __dadd_rn(ob_quiet, cst[k]);
+            const int ej = j * 16;
+            const char *ch_j = (const char *)sh.ch_prev + ej;           // (cost, history) of p = j
+            const char *acc_j = (const char *)(sh.acc + (j + n1));      // acc[(j - 2p + pp) + n1] = acc_j + low half
+            const char *jerk_j = (const char *)(jerk_row + j);
+            int be = -1;
+            for (int e = r * 16; e <= ej; e += 16 * ST_SPLIT) { // e = 16 * (j - p)
+                const double2 fsv = *(const double2 *)((const char *)sh.fs + e);
                 // the lanes of a wave hold neighbouring cells at nearly the same distance, so
                 // "no lane needs the front formula" is common (slow edges, obstacles far ahead)
                 // and decided for the whole wave
                 double obv;
-                if (RT > 0 && __ballot(d >= d_quiet) == 0ull) obv = ob_quiet;
-                else obv = cell.ob(s, sh.front[d]);
-                const double base = __dadd_rn(obv, sh.speed[d]);
-                if (cell.monotone && d >= d_lim && bp != 0x7fffffff && __dadd_rn(base, m_prev) > best) break;
-                // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136):
-                // what depends on p alone was looked up once for the layer
-                const int h = sh.hist[p];
-                const int n = j + (int)(short)(h & 0xffff);
-                const double jc = (i == 2) ? sh.jerk2[n + n1] : sh.jerk3[j + (h >> 16) + 2 * n1];
-                const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n1]), jc);
-                const double c = __dadd_rn(tot, sh.cost_prev[p]);
-                if (c <= best) { best = c; bp = p; }
+                if (RT > 0 && __ballot(e >= e_quiet) == 0ull) obv = ob_quiet;
+                else {
+                    const double fsum = __dadd_rn(fsv.x, s);
+                    obv = 0.0;
+#pragma unroll
+                    for (int k = 0; k < RT; ++k) {
+                        const unsigned ek = (k & 1) ? (fire[k >> 1] >> 16) : (fire[k >> 1] & 0xffffu);
+                        const double x = __dsub_rn(fsum, dn[k]);
+                        const double t = ((unsigned)e >= ek) ? __dmul_rn(1e3, __dmul_rn(x, x)) : cst[k];
+                        obv = (k == 0) ? t : __dadd_rn(obv, t); // 0.0 + t == t: every term is >= +0.0
+                    }
+                }
+                const double base = __dadd_rn(obv, fsv.y);
+                if (e >= e_brk && __dadd_rn(base, m_prev) > best) break;
+                // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
+                const double2 chv = *(const double2 *)(ch_j - e);
+                const int h = __double2loint(chv.y);
+                const double av = *(const double *)(acc_j + (int)(short)(h & 0xffff));
+                const double jv = *(const double *)(jerk_j + (h >> 16));
+                const double tot = __dadd_rn(__dadd_rn(base, av), jv);
+                const double c = __dadd_rn(tot, chv.x);
+                if (c <= best) { best = c; be = e; }
             }
+            if (be >= 0) bp = j - (be >> 4);
         }
         group_argmin<ST_SPLIT>(best, bp);
         if (live && r == 0) {
-            sh.cost_cur[j] = best;
+            sh.cost_cur(j) = best;
             sh.pre16[(size_t)i * N + j] = (short)bp;
             if (cost_g) cost_g[(size_t)i * N + j] = best;
             if (pre_g) pre_g[(size_t)i * N + j] = bp;
@@ -295,9 +360,9 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 }
 
 // One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
-//   cost_prev[N] cost_cur[N] front[N] speed[N] acc[2N] jerk2[2N] jerk3[4N]
-//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim | hist[N] i32
-//   | cell tables dn[r_tab][N] cst[r_tab][N] | quiet[N] i32
+//   fs[N][2] row0[N][2] row1[N][2] acc[2N] jerk2[2N] jerk3[4N]
+//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim
+//   | cell records [N][2 r_tab + 4] (see StTab)
 // TABLES: the cost / predecessor tables are written to global memory.
 // RTK >= 0: an instance for batches with at most RTK blocked intervals per layer (layers
 // with fewer are padded with intervals that add exact zeros); it holds one relaxation path
@@ -317,11 +382,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     }
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     StSh sh;
-    sh.cost_prev = smem;
-    sh.cost_cur = sh.cost_prev + N;
-    sh.front = sh.cost_cur + N;
-    sh.speed = sh.front + N;
-    sh.acc = sh.speed + N;         // index n + (n_s-1), n in [-(n_s-1), n_s-1]
+    sh.fs = smem;
+    sh.ch_prev = sh.fs + 2 * N;
+    sh.ch_cur = sh.ch_prev + 2 * N;
+    sh.acc = sh.ch_cur + 2 * N;    // index n + (n_s-1), n in [-(n_s-1), n_s-1]
     sh.jerk2 = sh.acc + 2 * N;     // same index, layer i == 2
     sh.jerk3 = sh.jerk2 + 2 * N;   // index m + 2(n_s-1), layers i >= 3
     sh.down = sh.jerk3 + 4 * N;
@@ -330,12 +394,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     double *red = last_col + n_t;
     sh.pre16 = (short *)(red + 8);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
-    sh.hist = d_lim_sh + 2;
     StTab tb; // placed by offset from smem so the pointers stay LDS pointers
-    const size_t tab_off = st_tab_offset(N, R_max, n_t);
-    tb.dn = smem + tab_off / 8;
-    tb.cst = tb.dn + (size_t)a.r_tab * N;
-    tb.quiet = (int *)(tb.cst + (size_t)a.r_tab * N);
+    tb.rec = smem + st_tab_offset(N, R_max, n_t) / 8;
+    tb.r_tab = a.r_tab;
+    tb.stride = st_rec_stride(a.r_tab);
 
     const double ds = a.ds, dt = a.dt, lim = a.speed_lim;
     const double v0 = a.cur_vel[b];
@@ -349,7 +411,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     // integer difference, evaluated with the reference's operations
     for (int d = tid; d < n_s; d += nt) {
         double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)d), ds), dt);
-        sh.front[d] = __dmul_rn(4.5, v);
+        sh.front(d) = __dmul_rn(4.5, v);
         double sc;
         if (v > lim) {
             sc = __dmul_rn(__dmul_rn(100.0, __dmul_rn(v, v)), dt);
@@ -359,7 +421,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             double dv = __ddiv_rn(__dsub_rn(v, lim), lim);
             sc = __dmul_rn(__dmul_rn(-100.0, dv), dt);
         }
-        sh.speed[d] = sc;
+        sh.speed(d) = sc;
     }
     for (int q = tid; q < 2 * n_s - 1; q += nt) {
         int n = q - (n_s - 1);
@@ -375,7 +437,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     }
     // row 0: cost 0, pre_ind -1 (st_map.py:86-91)
     for (int j = tid; j < N; j += nt) {
-        sh.cost_prev[j] = 0.0;
+        sh.cost_prev(j) = 0.0;
         sh.pre16[j] = -1;
         if (cost_g) cost_g[j] = 0.0;
         if (pre_g) pre_g[j] = -1;
@@ -403,13 +465,17 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
             sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
         }
-        for (int j = tid; j < n_s; j += nt) tb.quiet[j] = 0x7fffffff;
+        for (int j = tid; j < n_s; j += nt) {
+            tb.quiet(j)[0] = 0x7fffffff;
+            tb.quiet(j)[1] = 0;
+        }
         if (i >= 2) {
             // the predecessor chain of every cell of the layer below (final since the last barrier)
             for (int p = tid; p < n_s; p += nt) {
                 const int pp = sh.pre16[(size_t)(i - 1) * N + p];
                 const int ppp = sh.pre16[(size_t)(i - 2) * N + pp];
-                sh.hist[p] = ((pp - 2 * p) & 0xffff) | ((3 * pp - ppp - 3 * p) << 16);
+                const int lo = 8 * (pp - 2 * p);
+                sh.hist_prev(p) = (lo & 0xffff) | ((i == 2 ? lo : 8 * (3 * pp - ppp - 3 * p)) << 16);
             }
         }
         if (i + 1 < n_t) {
@@ -430,10 +496,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                 double jk = __ddiv_rn(ac, dt);
                 StCellLds cell;
                 cell.init(s, sh.down, sh.up, R);
-                double ob = cell.ob(s, sh.front[j]);
-                double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed[j]), __dmul_rn(__dmul_rn(ac, ac), dt)),
+                double ob = cell.ob(s, sh.front(j));
+                double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed(j)), __dmul_rn(__dmul_rn(ac, ac), dt)),
                                         __dmul_rn(__dmul_rn(jk, jk), dt));
-                sh.cost_cur[j] = best;
+                sh.cost_cur(j) = best;
                 sh.pre16[(size_t)i * N + j] = 0;
                 if (cost_g) cost_g[(size_t)i * N + j] = best;
                 if (pre_g) pre_g[(size_t)i * N + j] = 0;
@@ -441,14 +507,14 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             }
         } else if (RTK >= 0) {
             if constexpr (RTK >= 0) {
-                if (R <= RTK && R <= a.r_tab)
+                if (R <= RTK && RTK <= a.r_tab)
                     m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
                 else
                     m_loc = st_relax_layer<StCellLds>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
             }
-        } else if (R <= a.r_tab && R <= 8) {
+        } else if (R <= 8 && (R == 7 ? 8 : R) <= a.r_tab) { // 7 intervals run as 8 with one padded slot
 #define ST_SPLIT_CASE(RT)                                                                                   \
-    m_loc = N <= 48 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
+    m_loc = a.lanes_per_cell == 4 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
                     : st_relax_layer_split<RT, 8>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
             switch (R) {
             case 0: ST_SPLIT_CASE(0); break;
@@ -483,27 +549,26 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         m_loc = wave_min_f64(m_loc);
         if ((tid & (MP_WAVE - 1)) == 0) red[wave] = m_loc;
         __syncthreads();
-        if (tid == 0) last_col[i] = sh.cost_cur[n_s - 1];
+        if (tid == 0) last_col[i] = sh.cost_cur(n_s - 1);
         m_prev = red[0];
         for (int w = 1; w < nw; ++w) m_prev = red[w] < m_prev ? red[w] : m_prev;
         // the two cost rows swap roles; the next layer overwrites `red` and the other row
         // only after its own first barrier
-        double *row = sh.cost_prev;
-        sh.cost_prev = sh.cost_cur;
-        sh.cost_cur = row;
+        double *row = sh.ch_prev;
+        sh.ch_prev = sh.ch_cur;
+        sh.ch_cur = row;
     }
     __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
-        const double *cost_prev = sh.cost_prev;
         double min_i = last_col[1];
         int arg_i = 1;
         for (int i = 2; i < n_t; ++i)
             if (last_col[i] < min_i) { min_i = last_col[i]; arg_i = i; }
-        double min_j = cost_prev[0];
+        double min_j = sh.cost_prev(0);
         int arg_j = 0;
         for (int j = 1; j < n_s; ++j)
-            if (cost_prev[j] < min_j) { min_j = cost_prev[j]; arg_j = j; }
+            if (sh.cost_prev(j) < min_j) { min_j = sh.cost_prev(j); arg_j = j; }
         int end_i, end_j;
         if (min_i <= min_j) { end_i = arg_i; end_j = n_s - 1; }
         else { end_i = n_t - 1; end_j = arg_j; }
@@ -528,7 +593,7 @@ __global__ void st_dp_kernel(StDev a)
 #ifndef ST_WAVES_PER_EU
 #define ST_WAVES_PER_EU 6
 #endif
-template <int RTK, int SPLITK> // SPLITK lanes per cell: 4 on grids of up to 48 cells, else 8
+template <int RTK, int SPLITK> // SPLITK lanes per cell (st_lanes_per_cell)
 __attribute__((amdgpu_waves_per_eu(ST_WAVES_PER_EU, ST_WAVES_PER_EU))) __global__ void st_dp_r_kernel(StDev a)
 {
     st_dp_body<false, RTK, SPLITK>(a);
@@ -808,17 +873,16 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     }
     // cell tables: as many interval slots as fit next to everything else (at most r_max)
     int r_tab = r_max > 0 ? r_max : 1;
-    if (r_tab > 8) r_tab = 8; // the split path keeps a cell's intervals in registers
-    while (r_tab > 0 && (size_t)r_tab * n_s_max * 16 > 32 * 1024) --r_tab;
-    StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    if (r_tab > 8 || r_tab == 7) r_tab = 8; // the split path keeps a cell's intervals in registers (7 run as 8)
+    while (r_tab > 0 && st_tab_bytes(n_s_max, r_tab) > 40 * 1024) --r_tab;
+    StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, st_lanes_per_cell(B, n_s_max), n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // wide grid gets more lanes per layer
     if (B <= 512 && n_s_max > 64) threads = 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + (size_t)2 * r_tab * n_s_max * sizeof(double) +
-                 (size_t)n_s_max * sizeof(int);
+    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + st_tab_bytes(n_s_max, r_tab);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
@@ -827,10 +891,10 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // large batches with few intervals per layer (r_max is the caller's bound) take the
     // instance built for that bound and grid width class; MP_ST_GENERIC=1 keeps them on the
     // kernel that holds every path
-    const int rk = (B >= 2048 && r_max <= 8 && r_max <= r_tab && mp_knob_st_generic() != 1)
-                       ? (r_max == 7 ? 8 : (r_max < 0 ? 0 : r_max)) : -1;
+    int rk = r_max == 7 ? 8 : r_max;
+    if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() != 1)) rk = -1;
 #define ST_R_LAUNCH(RT)                                                                      \
-    if (n_s_max <= 48) hipLaunchKernelGGL((st_dp_r_kernel<RT, 4>), grid, block, lds, st, a); \
+    if (a.lanes_per_cell == 4) hipLaunchKernelGGL((st_dp_r_kernel<RT, 4>), grid, block, lds, st, a); \
     else hipLaunchKernelGGL((st_dp_r_kernel<RT, 8>), grid, block, lds, st, a)
     if (cost || pre) hipLaunchKernelGGL(st_dp_kernel<true>, grid, block, lds, st, a);
     else switch (rk) {
