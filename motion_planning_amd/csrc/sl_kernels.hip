@@ -704,7 +704,8 @@ __global__ void sl_plan_kernel(SlDev a)
     // neither the other lanes' nodes nor the layer minimum nor a barrier.  (The reference's
     // absolute-s evaluation makes w_inv fall like s^-8, so this holds from the first few
     // layers on.)  0 switches the shortcut off.
-    const double gap2_min = (!rstride && n_l > 1 && laySorted[0] && gap_min > 0.0 && gap_min < MP_INF)
+    // (cG >= 0: straight edges then cost at least nothing, so costs never decrease along a lane)
+    const double gap2_min = (!rstride && n_l > 1 && laySorted[0] && gap_min > 0.0 && gap_min < MP_INF && cG >= 0.0)
                                 ? gap_min * gap_min * (1.0 - 1e-9) : 0.0;
     __syncthreads(); // red / redmax are reused by the layer loop
 
@@ -753,6 +754,14 @@ __global__ void sl_plan_kernel(SlDev a)
             unsigned rec_n = recL[s];
             int k_n = runL[s];
             const int k_run = __builtin_amdgcn_readfirstlane(g_K);
+            // the two sums a layer can add to this lane's cost, rounded as the general path
+            // rounds them (edge first, then edge + cost)
+            const double step_free = g_own + 0.0, step_hit = g_own + pen;
+            // Costs never decrease along a lane, so "every cost of the layer exceeds the abort
+            // threshold" holds from some layer of the run on; each lane counts the layers at
+            // which its own cost was still within the threshold, and the wave looks at the
+            // counts once, behind the run.
+            int n_within = 0;
             while (true) {
                 const unsigned rec = __builtin_amdgcn_readfirstlane(rec_n);
                 const int k = __builtin_amdgcn_readfirstlane(k_n);
@@ -760,33 +769,45 @@ __global__ void sl_plan_kernel(SlDev a)
                 rec_n = recL[s + 1]; // k != 0: layer s + 1 exists
                 k_n = runL[s + 1];
                 const int ne = (int)(rec >> 16), off = (int)(rec & 0xffffu);
-                double best = 0.0;
-                if (is_target) {
-                    bool hit = false;
-                    for (int e = 0; e < ne; ++e) {
-                        // pair_hit at dl = 0: the sample sits on this lane
-                        const double d = l_cur - pair_ol[off + e];
-                        hit |= fma(d, d, pair_ds2[off + e]) < r2;
+                // pair_hit at dl = 0 (the sample sits on this lane), four pairs per round trip
+                // to LDS: slots behind the layer's pairs are read (they lie inside the store
+                // or the arrays behind it) and ignored
+                const double *po = pair_ol + off, *pd = pair_ds2 + off;
+                bool hit = false;
+                if (ne > 0) {
+                    const double o0 = po[0], o1 = po[1], o2 = po[2], o3 = po[3];
+                    const double q0 = pd[0], q1 = pd[1], q2 = pd[2], q3 = pd[3];
+                    const double d0 = l_cur - o0, d1 = l_cur - o1, d2 = l_cur - o2, d3 = l_cur - o3;
+                    hit = fma(d0, d0, q0) < r2;
+                    hit |= (ne > 1) & (fma(d1, d1, q1) < r2);
+                    hit |= (ne > 2) & (fma(d2, d2, q2) < r2);
+                    hit |= (ne > 3) & (fma(d3, d3, q3) < r2);
+                    for (int e = 4; e < ne; ++e) {
+                        const double d = l_cur - po[e];
+                        hit |= fma(d, d, pd[e]) < r2;
                     }
-                    const double e = g_own + (hit ? pen : 0.0);
-                    best = e + cost_own;
-                    cost_own = best;
-                    if (MAPS) {
-                        const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
-                        if (a.cost_map) a.cost_map[o] = best;
-                        if (a.index_map) a.index_map[o] = tid;
-                    }
-                    if constexpr (COUNT) ++n_eval;
+                }
+                cost_own = (hit ? step_hit : step_free) + cost_own;
+                n_within += !(cost_own > abort_thr);
+                if (MAPS && is_target) {
+                    const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
+                    if (a.cost_map) a.cost_map[o] = cost_own;
+                    if (a.index_map) a.index_map[o] = tid;
                 }
                 if constexpr (COUNT) {
+                    if (is_target) ++n_eval;
                     n_eval_seen = n_eval;
                     if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, 1ull);
                 }
-                const bool all_above = __all(!is_target || best > abort_thr);
-                if (all_above && (tid & (MP_WAVE - 1)) == 0) {
-                    if (atomicAdd(&excL[s], 1) == nw - 1) atomicMin(first_ex, s);
-                }
                 ++s;
+            }
+            if (s != s_in) {
+                // the run's first layer at which every target of this wave was above the threshold
+                int last_within = is_target ? n_within : 0;
+                for (int m = 32; m >= 1; m >>= 1) last_within = max(last_within, __shfl_xor(last_within, m, MP_WAVE));
+                if ((tid & (MP_WAVE - 1)) == 0)
+                    for (int q = s_in + last_within; q < s; ++q)
+                        if (atomicAdd(&excL[q], 1) == nw - 1) atomicMin(first_ex, q);
             }
             if (s != s_in) { // back to the general path at layer s (still one that needs no exchange)
                 done = s;
