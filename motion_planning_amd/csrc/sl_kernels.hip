@@ -226,6 +226,29 @@ struct Collider {
         }
         return h;
     }
+    // True only if the edges into lateral offset l2 from EVERY source offset in [la, lb] hit
+    // something: the sample of pair e sits at l1 + h0*(l2 - l1), linear in l1, so its squared
+    // distance to the obstacle is largest at one end of the range; both ends inside the
+    // radius with a margin far above rounding means every source in between hits as well.
+    // Conservative (false when in doubt or when no pair list exists); looks at 32 pairs at most.
+    __device__ __forceinline__ bool hit_from_all(double l2, double la, double lb) const
+    {
+        const double r2m = r2 * (1.0 - 1e-9);
+        auto all = [&](double h0e, double ole, double ds2e) {
+            const double da = fma(l2 - la, h0e, la) - ole, db = fma(l2 - lb, h0e, lb) - ole;
+            const double a2 = da * da, b2 = db * db;
+            return (a2 > b2 ? a2 : b2) + ds2e < r2m;
+        };
+        bool h = false;
+        if constexpr (NE > 0) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) h |= all(h0[e], ol[e], ds2[e]);
+        } else if constexpr (NE == -1) {
+            const int n = n_ent < 32 ? n_ent : 32;
+            for (int e = 0; e < n; ++e) h |= all(e_h0[e], e_ol[e], e_ds2[e]);
+        }
+        return h;
+    }
 };
 
 // The (sample, obstacle) pairs of every layer of one scenario, kept in LDS for
@@ -451,22 +474,33 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
                                                const Collider<NE> &col, int *bj_out, int *n_eval = nullptr)
 {
     const int l2 = threadIdx.x;
-    auto eval = [&](double l1, double cp, double dl) {
-        const double u = l1 - src.mid;
-        double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
-        e += col.hit(l1, dl) ? pen : 0.0;
-        return e + cp;
-    };
     const int j0 = min(l2, n_src - 1);
     double2 lc = src.lc[j0];
-    double best = eval(lc.x, lc.y, l2v - lc.x);
+    double best;
+    bool hit0;
+    {
+        const double l1 = lc.x, dl = l2v - lc.x;
+        const double u = l1 - src.mid;
+        double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
+        hit0 = col.hit(l1, dl);
+        e += hit0 ? pen : 0.0;
+        best = e + lc.y;
+    }
     int bj = j0;
     if constexpr (COUNT) ++*n_eval;
+    // A target that cannot be entered without a collision (an obstacle reaches a place every
+    // incoming edge passes, e.g. the node itself) pays the penalty on every edge.  Its window
+    // would stay as wide as the penalty and the walk would price the whole row; instead the
+    // penalty becomes part of every candidate's lower bound and drops out of the comparison.
+    double pen_all = 0.0;
+    if (hit0 && sorted && n_src > 1 && w_inv > 0.0 && col.hit_from_all(l2v, src.lc[0].x, src.lc[n_src - 1].x))
+        pen_all = pen * (1.0 - 1e-12);
     // candidates with dl^2 above w2 cannot beat `best`: their cost is at least
-    // m_prev + cSH*dl^2 up to rounding, which the slack terms cover
+    // m_prev + cSH*dl^2 (+ the penalty where no edge avoids it) up to rounding, which the
+    // slack terms cover
     // (the window follows `best` down: a free edge found next to a blocked one ends the walk)
     auto window = [&](double bst) {
-        double gap = bst - m_prev;
+        double gap = (bst - m_prev) - pen_all;
         gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(bst));
         return gap * w_inv;
     };
@@ -497,7 +531,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     // test are skipped.  On a layer whose costs rise steeply away from the ego (the first
     // ones) most of the window falls to this test.
     auto cannot_win = [&](double dl2, double cp) {
-        double gap = best - cp;
+        double gap = (best - cp) - pen_all;
         gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
         return w_inv > 0.0 && dl2 > gap * w_inv;
     };

@@ -312,6 +312,35 @@ def test_sl_empty_edge_and_capacity_status():
     assert r["status"] == _lib.MP_SL_FOUND                  # no obstacles: empty edge costs 0
 
 
+@pytest.mark.parametrize("n_l", [24, 128])
+def test_sl_targets_that_no_edge_enters_without_a_collision(oracle, n_l):
+    """The reference evaluates an edge quintic at the absolute arc length (path_planner.py:146-148),
+    so the first sample of the second layer sits at the TARGET's lateral offset whatever the
+    source: an obstacle next to it blocks every edge into the targets it reaches, and their
+    costs all carry the penalty.  Also an obstacle on a node of a later layer."""
+    rng = np.random.default_rng(31 + n_l)
+    B, n_s = 6, 7
+    s_map, l_map, ego, _, _ = random_batch(rng, B, n_s, n_l, 4.0, 1, 0.3, 0.8)
+    obs = []
+    for b in range(B):
+        o = [[s_map[b, 0, 0] + rng.uniform(-0.1, 0.1), rng.uniform(-1.0, 1.0)],        # first sample of layer 1
+             [s_map[b, 2, 0], rng.uniform(-1.0, 1.0)], [s_map[b, 4, 0] - 0.2, 0.3]]    # on / next to later nodes
+        obs.append(np.array(o[: 1 + b % 3]))
+    ob_dist = rng.uniform(0.3, 0.9, B)
+    mid_l = int((n_l - 1) / 2)
+    res = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False)
+    res_split, edges = gpu_sl(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=False, split=True)
+    n_dead = 0
+    for b in range(B):
+        ref = oracle.sl_find_path(s_map[b], l_map[b], mid_l, ego[b], obs[b], ob_dist[b], no_early_exit=True,
+                                  want_edges=True)
+        assert_sl_parity(res[b], ref, ref["edge_cost"])
+        assert np.array_equal(res[b]["cost_map"], res_split[b]["cost_map"])
+        assert np.array_equal(res[b]["index_map"], res_split[b]["index_map"])
+        n_dead += int((ref["edge_cost"][1] >= 3e4).all(axis=1).sum())     # targets of layer 1 whose every edge is penalised
+    assert n_dead > 0
+
+
 def gpu_sl_nodes(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, n_layers=None):
     """Per-node edge kernel + DP kernel; returns (list of result dicts, edge tensor, edge status)."""
     import torch
