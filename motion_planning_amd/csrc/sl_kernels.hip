@@ -85,6 +85,9 @@ __device__ __forceinline__ LayerConst layer_const(const LayerGeom &g, double p1s
                                                   double cG, double cS)
 {
     const double T = p2s - p1s;
+    // one division per layer: the derivatives' scale factors 1/T, 1/T^2, 1/T^3 (one thread
+    // works through a layer's samples, and a double division is some thirty instructions)
+    const double i1 = 1.0 / T, i2 = i1 * i1, i3 = i2 * i1;
     double sa = 0.0, sb = 0.0, sq = 0.0;
     for (int k = 0; k < g.K; ++k) {
         const double x = arange_value(k, g.n, p1s, p2s, d_s, g.delta);
@@ -92,9 +95,9 @@ __device__ __forceinline__ LayerConst layer_const(const LayerGeom &g, double p1s
         const double t2 = tau * tau;
         const double h0 = t2 * tau * (10.0 + tau * (-15.0 + 6.0 * tau));
         const double w = tau - 1.0;
-        const double h1 = 30.0 * t2 * w * w / T;
-        const double h2 = 60.0 * tau * (1.0 + tau * (-3.0 + 2.0 * tau)) / (T * T);
-        const double h3 = 60.0 * (1.0 + tau * (-6.0 + 6.0 * tau)) / (T * T * T);
+        const double h1 = 30.0 * t2 * w * w * i1;
+        const double h2 = 60.0 * tau * (1.0 + tau * (-3.0 + 2.0 * tau)) * i2;
+        const double h3 = 60.0 * (1.0 + tau * (-6.0 + 6.0 * tau)) * i3;
         sa += h0;
         sb += h0 * h0;
         sq += h1 * h1 + h2 * h2 + h3 * h3;
@@ -861,8 +864,8 @@ __global__ void sl_plan_kernel(SlDev a)
             // per layer, so every layer's can be had now (read from layer 2's end on, behind
             // the barrier that ends this layer)
             for (int q = tid; q < n_s; q += nt) {
-                double c = c_top;
-                for (int t = 1; t < q; ++t) c = (c + g_max + pen) * (1.0 + 1e-12);
+                // at least what q - 1 steps of c -> (c + g_max + pen) * (1 + 1e-12) come to
+                const double c = q < 2 ? c_top : (c_top + (double)(q - 1) * (g_max + pen)) * (1.0 + 2e-12 * (double)q);
                 const bool loc = q >= 2 && is_local(c, layW[q]);
                 locL[q] = loc;
                 const int kq = layK[q];
