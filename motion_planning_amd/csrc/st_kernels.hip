@@ -245,8 +245,10 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // (every record's quiet word and flag word were reset before the barrier in front of this call)
     const double front_step = sh.front(n_s > 1 ? 1 : 0);
     const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
+    // q / n_s by multiplication: exact while q * n_s < 2^32 (q < 8 * n_s, n_s <= 1024)
+    const unsigned n_s_magic = 0xffffffffu / (unsigned)n_s + 1u;
     for (int q = tid; q < n_s * RT; q += nt) {
-        const int k = q / n_s, j = q - k * n_s;
+        const int k = (int)__umulhi((unsigned)q, n_s_magic), j = q - k * n_s;
         double *rec = tb.cell(j);
         double dnk = MP_INF, ck = 0.0; // slots beyond the layer's intervals never fire and add exact zeros
         unsigned e_fire = 0xffffu;
