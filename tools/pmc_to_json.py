@@ -19,8 +19,10 @@ k = {}
 for line in open(src):
     m = re.match(r"(\S.*?)\s+(\S+)\s+n=\d+\s+mean=(\S+)", line)
     name = m.group(1).split("<")[0] if m else None   # template instances count under the kernel's name
+    if name == "st_dp_r_kernel":
+        name = "st_dp_kernel"   # the instances per interval bound are the same kernel body
     if name in KERNELS:
-        if m.group(1).startswith("sl_plan_kernel<") and m.group(1).count(",") == 2:
+        if m.group(1).startswith("sl_plan_kernel<") and m.group(1).rstrip(">").endswith(", true"):
             continue   # the counting instance (third template argument) is not the product kernel
         k.setdefault(name, {})[m.group(2)] = float(m.group(3))
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles",
