@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmplattice.so")
+# MP_LIB_PATH: another build of the library (A/B timing of two builds in one session)
+LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
 MP_VERSION = 121   # MP_VERSION of include/mplattice.h this binding was written for

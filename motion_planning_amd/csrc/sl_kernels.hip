@@ -1091,7 +1091,7 @@ __global__ void sl_plan_kernel(SlDev a)
 // sl_plan_kernel, bit for bit.
 // Dynamic LDS (n_sm = layer slots, cap = pair_cap):
 //   layA layQ layP2 layMid [n_sm] | pairs[3][cap] | lc[2][W] double2 | g[2][W] | red[2][16]
-//   | layK[n_sm] int | cntL[n_sm] int | offL[n_sm] u16 | idx8[n_sm*n_l] u8
+//   | hit_w[16] u64 | layK[n_sm] int | cntL[n_sm] int | offL[n_sm] u16 | idx8[n_sm*n_l] u8
 template <int W, bool MAPS>
 __global__ void sl_plan_narrow_kernel(SlDev a)
 {
@@ -1111,7 +1111,8 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     double2 *lc_all = (double2 *)(pair_ds2 + cap + (cap & 1));
     double *g_all = (double *)(lc_all + 2 * W);
     double *red = g_all + 2 * W;
-    int *layK = (int *)(red + 32);
+    unsigned long long *hit_w = (unsigned long long *)(red + 32); // [16]: per wave, which edges its share of the pairs hits
+    int *layK = (int *)(hit_w + 16);
     int *cntL = layK + n_sm;
     unsigned short *offL = (unsigned short *)(cntL + n_sm);
     unsigned char *idx8 = (unsigned char *)(offL + n_sm + (n_sm & 1));
@@ -1211,19 +1212,28 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
             // Up to 5 lanes: the edges of a layer fill at most half of the (single) wave, so
             // the wave holds every edge 64/Es times (Es = 4, 16 or 32 lanes per copy) and each
             // copy takes every (64/Es)-th pair; a ballot brings the copies' verdicts together.
+            // A crowded scene runs several waves per scene (they share the work of laying out
+            // the pairs); every wave then takes its share of the layer's pairs as well and the
+            // verdicts meet in LDS.
             const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
             const int n_e = n_l * n_l, Es = n_e <= 4 ? 4 : (n_e <= 16 ? 16 : 32), P = MP_WAVE / Es;
-            const int ee = lane & (Es - 1), part = lane / Es;
+            const int ee = lane & (Es - 1), part = wave * P + lane / Es;
             const int t2 = ee / n_l, j2 = ee - t2 * n_l;
             const bool e_valid = ee < n_e && j2 < n_src;
-            // the edge's end points, from the lanes that hold them in the (t, j) layout
-            const double l2b = __shfl(l2v, e_valid ? t2 * W : 0, MP_WAVE);
-            const double l1b = __shfl(lcj.x, e_valid ? j2 : 0, MP_WAVE);
+            // the edge's end points: the values the lanes of the (t, j) layout hold
+            const double l2b = e_valid ? lbase[(size_t)s * rstride + t2] : 0.0;
+            const double l1b = e_valid ? lc_all[buf * W + j2].x : 0.0;
             const double dlb = l2b - l1b;
             bool h = false;
-            for (int e = part; e < n_ent; e += P) h |= pair_hit(l1b, dlb, e_h0[e], e_ol[e], e_ds2[e], r2);
+            for (int e = part; e < n_ent; e += P * nw) h |= pair_hit(l1b, dlb, e_h0[e], e_ol[e], e_ds2[e], r2);
             unsigned long long m = __ballot(h && e_valid);
             for (int p = 1; p < P; ++p) m |= m >> (p * Es); // bit e of the low copy: any copy hit
+            if (nw > 1) {
+                if (lane == 0) hit_w[wave] = m;
+                __syncthreads();
+                m = hit_w[0];
+                for (int w = 1; w < nw; ++w) m |= hit_w[w];
+            }
             hit = valid && ((m >> (t * n_l + j)) & 1ull);
         } else if (ent_stored) {
             const double *e_h0 = pair_h0 + ent_off, *e_ol = pair_ol + ent_off, *e_ds2 = pair_ds2 + ent_off;
@@ -1625,11 +1635,11 @@ static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
     return (bytes + 15) & ~(size_t)15;
 }
 
-#define SLN_CAP_MAX 384 // narrow kernel: upper limit of its pair store (9 KB)
+#define SLN_CAP_MAX 384 // narrow kernel: upper limit of its pair store per wave (9 KB)
 
 static size_t sl_narrow_lds_bytes(int n_s, int n_l, int W, int cap)
 {
-    size_t d = (size_t)4 * n_s + (n_s & 1) + 3 * (size_t)cap + (cap & 1) + 4 * W + 2 * W + 32;
+    size_t d = (size_t)4 * n_s + (n_s & 1) + 3 * (size_t)cap + (cap & 1) + 4 * W + 2 * W + 32 + 16;
     size_t bytes = d * sizeof(double) + 2 * (size_t)n_s * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short) +
                    (size_t)n_s * n_l;
     return (bytes + 15) & ~(size_t)15;
@@ -1716,9 +1726,18 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     const bool narrow_ok = mp_knob_sl_narrow() != 0;
     if (n_l <= 16 && narrow_ok && !n_evaluated) {
         const int W = n_l <= 2 ? 2 : (n_l <= 4 ? 4 : (n_l <= 8 ? 8 : 16));
-        const int threads = ((n_l * W + 63) / 64) * 64;
+        int threads = ((n_l * W + 63) / 64) * 64;
+        int cap_max = SLN_CAP_MAX;
+        if (batch->ob_stride > 128 && n_l * n_l <= 32) {
+            // a crowded scene: laying out thousands of pairs and testing them against every edge
+            // is the work, and one wave per scene leaves the launch waiting for its slowest
+            // scene; two waves share it, with a store twice the size (four waves were slower: what a
+            // layer costs besides its pairs is paid by every wave)
+            threads = 128;
+            cap_max = 2 * SLN_CAP_MAX;
+        }
         int ncap = (7 * batch->ob_stride) / 2;
-        ncap = ncap > SLN_CAP_MAX ? SLN_CAP_MAX : ncap;
+        ncap = ncap > cap_max ? cap_max : ncap;
         if (mp_knob_sl_pair_cap() >= 0) ncap = mp_knob_sl_pair_cap(); // tests: force refills
         ncap = ncap < 2 ? 2 : (ncap > 2048 ? 2048 : ncap);
         ncap += ncap & 1;

@@ -12,6 +12,8 @@
 // an integer difference (speed on j-p, acceleration on j-2p+pp, jerk on
 // j-3p+3pp-ppp) are tabulated once per scenario in LDS, which removes all
 // divisions from the edge loop without changing a single bit.
+#include <type_traits>
+
 #include "mp_device.h"
 
 struct StDev {
@@ -318,7 +320,10 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
             const char *acc_j = (const char *)(sh.acc + (j + n1));      // acc[(j - 2p + pp) + n1] = acc_j + low half
             const char *jerk_j = (const char *)(jerk_row + j);
             int be = -1;
-            for (int e = r * 16; e <= ej; e += 16 * ST_SPLIT) { // e = 16 * (j - p)
+            // one step of the walk at e = 16 * (j - p); FIRST: the lane's first step, where
+            // nothing can be pruned yet and the candidate is the best so far whatever it costs
+            auto step = [&](int e, auto first) -> bool {
+                constexpr bool FIRST = decltype(first)::value;
                 const double2 fsv = *(const double2 *)((const char *)sh.fs + e);
                 // the lanes of a wave hold neighbouring cells at nearly the same distance, so
                 // "no lane needs the front formula" is common (slow edges, obstacles far ahead)
@@ -337,7 +342,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                     }
                 }
                 const double base = __dadd_rn(obv, fsv.y);
-                if (e >= e_brk && __dadd_rn(base, m_prev) > best) break;
+                if constexpr (!FIRST)
+                    if (e >= e_brk && __dadd_rn(base, m_prev) > best) return true;
                 // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
                 const double2 chv = *(const double2 *)(ch_j - e);
                 const int h = __double2loint(chv.y);
@@ -345,7 +351,14 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 const double jv = *(const double *)(jerk_j + (h >> 16));
                 const double tot = __dadd_rn(__dadd_rn(base, av), jv);
                 const double c = __dadd_rn(tot, chv.x);
-                if (c <= best) { best = c; be = e; }
+                if (FIRST || c <= best) { best = c; be = e; }
+                return false;
+            };
+            int e = r * 16;
+            if (e <= ej) {
+                step(e, std::true_type());
+                for (e += 16 * ST_SPLIT; e <= ej; e += 16 * ST_SPLIT)
+                    if (step(e, std::false_type())) break;
             }
             if (be >= 0) bp = j - (be >> 4);
         }
