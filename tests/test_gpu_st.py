@@ -81,11 +81,13 @@ def test_st_random_vs_oracle(oracle, n_s_hi, B):
     assert torch.equal(out["path_s_ind"], out_nt["path_s_ind"]) and torch.equal(out["path_len"], out_nt["path_len"])
 
 
-@pytest.mark.parametrize("n_s_hi,r_max", [(97, 5), (40, 5), (97, 0), (70, 1), (97, 3), (60, 7), (97, 8)])
+@pytest.mark.parametrize("n_s_hi,r_max", [(97, 5), (40, 5), (97, 0), (70, 1), (97, 3), (60, 7), (97, 8), (128, 4),
+                                            (129, 4), (200, 2)])
 def test_st_large_batch_instances_match_the_general_kernel(oracle, n_s_hi, r_max, knob):
     """Batches of 2048 or more scenarios with at most 8 interval slots per layer run on a
     kernel instance built for that bound (layers with fewer intervals are padded with
-    intervals that add exact zeros) and for the grid's width class; the kernel that holds
+    intervals that add exact zeros) and for the grid's width class (4 lanes per cell up to 128
+    cells, 8 beyond); the kernel that holds
     every path (knob MP_ST_GENERIC=1) must give the same paths, and the tables it writes
     must match the oracle on a sample."""
     import torch
