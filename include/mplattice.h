@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 121
+#define MP_VERSION 122
 
 /* host-side return codes */
 #define MP_OK 0
@@ -126,6 +126,20 @@ int mp_set_knob(const char *name, int32_t value);
 int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
                double *best_cost, void *stream);
+
+/* mp_sl_plan with the workgroups of the fused kernel launched heaviest scenario
+ * first.  No counterpart in the reference (its planner handles one scenario at a
+ * time, path_planner.py:66-88); a batch whose plans differ in length ends when
+ * its last long plan does, and launched in the caller's order a long one may
+ * start last.  order_ws: 2*B int32 of device scratch, contents irrelevant on
+ * entry and on return (weights in the first half, the order in the second); two
+ * small launches in front of the kernel fill it.  The weight is a guess from the
+ * obstacles near the first layers and decides nothing but the order: outputs
+ * are those of mp_sl_plan, bit for bit.  Lattices of up to 16 lanes (their
+ * kernel takes a wave or two per scenario) ignore the workspace. */
+int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
+                       int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+                       double *best_cost, int32_t *order_ws, void *stream);
 
 /* Measurement aid, no counterpart in the reference: mp_sl_plan (maps not
  * written) by an instance of the same kernel that also counts the lattice edges

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
-MP_VERSION = 121   # MP_VERSION of include/mplattice.h this binding was written for
+MP_VERSION = 122   # MP_VERSION of include/mplattice.h this binding was written for
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
@@ -68,6 +68,7 @@ SIGNATURES = {
     "mp_last_error": (C.c_char_p, []),
     "mp_set_knob": (C.c_int, [C.c_char_p, C.c_int32]),
     "mp_sl_plan": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 7),
+    "mp_sl_plan_ordered": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 8),
     "mp_sl_plan_counted": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams)] + [_vp] * 6),
     "mp_sl_edge_cost": (C.c_int, [C.POINTER(SlBatch), C.POINTER(SlParams), _vp, _vp, _vp]),
     "mp_sl_edge_cost_nodes": (C.c_int, [C.c_int32] * 3 + [_vp] * 5 + [C.c_int32] + [_vp] * 3

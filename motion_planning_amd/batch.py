@@ -90,10 +90,12 @@ class SLBatch:
 
 
 class SLPlanOut:
-    """Pre-allocated outputs of one SL plan call (reusable across calls)."""
+    """Pre-allocated outputs of one SL plan call (reusable across calls), and the scratch the
+    library orders its workgroups in (heaviest scenario first)."""
 
     def __init__(self, B, n_s, n_l, want_maps=True, device=None):
         dev = device or _dev()
+        self.order_ws = torch.empty(2 * B, dtype=torch.int32, device=dev)
         self.cost_map = torch.empty((B, n_s, n_l), dtype=torch.float64, device=dev) if want_maps else None
         self.index_map = torch.empty((B, n_s, n_l), dtype=torch.int32, device=dev) if want_maps else None
         self.path_idx = torch.empty((B, n_s), dtype=torch.int32, device=dev)
@@ -102,11 +104,18 @@ class SLPlanOut:
         self.best_cost = torch.empty(B, dtype=torch.float64, device=dev)
 
 
-def sl_plan(batch, params=None, out=None, want_maps=True):
-    """Fused SL path DP (replaces PathPlanner.find_path, path_planner.py:66-101)."""
+def sl_plan(batch, params=None, out=None, want_maps=True, ordered=True):
+    """Fused SL path DP (replaces PathPlanner.find_path, path_planner.py:66-101).
+    ordered=False launches the scenarios in the caller's order (mp_sl_plan) instead of
+    heaviest first (mp_sl_plan_ordered); the results are the same."""
     params = params or sl_params(n_l=batch.n_l)
     out = out or SLPlanOut(batch.B, batch.n_s, batch.n_l, want_maps)
     cs = batch.c_struct()
+    if ordered and out.order_ws.numel() >= 2 * batch.B:
+        check(lib().mp_sl_plan_ordered(C.byref(cs), C.byref(params), _p(out.cost_map), _p(out.index_map),
+                                       _p(out.path_idx), _p(out.status), _p(out.layers_done), _p(out.best_cost),
+                                       _p(out.order_ws), _stream()), "mp_sl_plan_ordered")
+        return out
     check(lib().mp_sl_plan(C.byref(cs), C.byref(params), _p(out.cost_map), _p(out.index_map), _p(out.path_idx),
                            _p(out.status), _p(out.layers_done), _p(out.best_cost), _stream()), "mp_sl_plan")
     return out

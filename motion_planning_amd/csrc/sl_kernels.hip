@@ -47,6 +47,7 @@ struct SlDev {
     double *edge_cost; // edge-tensor kernel only
     int32_t pair_cap;  // fused kernel: (sample, obstacle) pairs the LDS pair store holds per scenario
     unsigned long long *n_evaluated; // counting instance of the fused kernel only: edges priced, summed over the batch
+    const int32_t *order;            // fused kernel: workgroup i plans scenario order[i] (null: scenario i)
 };
 
 struct LayerGeom {
@@ -615,7 +616,8 @@ __global__ void sl_plan_kernel(SlDev a)
     int n_eval = 0, n_eval_seen = 0;
     if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int n_l = a.in.n_l, n_sm = a.in.n_s; // n_sm: layer slots per scenario in every array
     const int n_s = scenario_layers(a.in, b);  // layers this scenario uses
     const int wave = tid / MP_WAVE, nw = nt / MP_WAVE;
@@ -1075,6 +1077,101 @@ __global__ void sl_plan_kernel(SlDev a)
             a.layers_done[b] = done;
             if (a.best_cost) a.best_cost[b] = (status == MP_SL_FOUND) ? c : __builtin_nan("");
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Order of the workgroups.  A plan's time is mostly decided by its first layers: where an
+// obstacle blocks a stretch of a target's sources the walk prices candidates one after the
+// other, and such a scenario takes up to three times as long as the median.  Workgroups are
+// handed to the CUs in launch order, so a batch of a few rounds of workgroups ends when the
+// last long plan does; with the long ones launched first the short ones fill in behind them
+// (on the benchmark batch 0.24 -> 0.18 ms).  The weight is a guess and only decides the
+// order: every scenario is planned by the same code whatever its position.
+//
+// sl_weight_kernel: one wave per scenario, lanes over the obstacles.  For the pairs of the
+// first three walking layers, the number of source lanes the pair blocks for a target: the
+// sample sits at l1 + h0*(l2 - l1), so the blocked sources span 2*rho / |1 - h0| (rho: what
+// is left of the radius at the pair's arc-length gap).  The sum goes into one of 16 bins
+// (its binary logarithm).
+__global__ void sl_weight_kernel(SlDev a, int32_t *key)
+{
+    const int lane = threadIdx.x & (MP_WAVE - 1);
+    const int b = blockIdx.x * (blockDim.x / MP_WAVE) + threadIdx.x / MP_WAVE;
+    if (b >= a.in.B) return;
+    const int n_l = a.in.n_l, n_sm = a.in.n_s;
+    const int n_s = scenario_layers(a.in, b);
+    const double *s_layers = a.in.s_layers + (size_t)b * n_sm;
+    const double *lbase = a.in.l_map + (size_t)b * a.in.l_bstride;
+    const double *ob_s = a.in.ob_s + (size_t)b * a.in.ob_stride;
+    const double *ob_l = a.in.ob_l + (size_t)b * a.in.ob_stride;
+    const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride);
+    const double r = a.in.ob_dist[b], r2 = r * r, d_s = a.p.d_s;
+    double w = 0.0;
+    if (n_l > 1 && n_ob > 0 && r > 0.0) {
+        const double l_a = lbase[0], l_b = lbase[n_l - 1];
+        const double l_lo = fmin(l_a, l_b), l_hi = fmax(l_a, l_b);
+        const double gap = (l_hi - l_lo) / (double)(n_l - 1);
+        const double lanes_per_m = gap > 0.0 ? 1.0 / gap : 0.0;
+        const int s_end = n_s < 3 ? n_s : 3; // layers 1 and 2: their windows are the widest
+        // (single precision is plenty for a guess)
+        for (int s = 1; s < s_end && gap > 0.0; ++s) {
+            const double p1s = s_layers[s - 1], p2s = s_layers[s];
+            const double rr = r * 1.000001 + 1e-9;
+            if (__ballot(lane < n_ob) == 0ull) break;
+            const LayerGeom g = layer_geom(p1s, p2s, d_s, n_ob);
+            if (g.K < 0) continue;
+            const float inv_T = 1.0f / (float)(p2s - p1s);
+            for (int o = lane; o < n_ob; o += MP_WAVE) {
+                const double os = ob_s[o], ol = ob_l[o];
+                if (os < p1s - rr || os > p2s + rr || !(ol > l_lo - r - 1.0 && ol < l_hi + r + 1.0)) continue;
+                for_each_near_sample(g, p1s, p2s, d_s, os, r, r2, [&](int, double x, double ds2) {
+                    const float tau = (float)x * inv_T;
+                    const float h0 = tau * tau * tau * (10.0f + tau * (-15.0f + 6.0f * tau));
+                    const float am = fabsf(1.0f - h0);
+                    const float span = 2.0f * sqrtf((float)(r2 - ds2)) * (float)lanes_per_m;
+                    // a sample that sits at the target's own offset blocks the target for every
+                    // source; the walk treats such targets cheaply, so they count little
+                    const float lanes = am > 1e-4f ? span / am : 0.2f * span;
+                    w += (double)fminf(lanes, (float)n_l);
+                });
+            }
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) w += __shfl_xor(w, m, MP_WAVE);
+    if (lane == 0) {
+        int bin = 0;
+        if (w >= 1.0) {
+            const unsigned u = w < 1e9 ? (unsigned)w : 1000000000u;
+            bin = 32 - __builtin_clz(u);
+            bin = bin > 15 ? 15 : bin;
+        }
+        key[b] = bin;
+    }
+}
+
+// sl_order_kernel: one workgroup; a counting sort of the scenarios by bin, heaviest bin
+// first (the order inside a bin is whatever the atomics give).
+__global__ void sl_order_kernel(int B, const int32_t *key, int32_t *order)
+{
+    __shared__ int cnt[16], base[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 16) cnt[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) atomicAdd(&cnt[key[b] & 15], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 15; k >= 0; --k) {
+            base[k] = run;
+            run += cnt[k];
+            cnt[k] = 0;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) {
+        const int k = key[b] & 15;
+        order[base[k] + atomicAdd(&cnt[k], 1)] = b;
     }
 }
 
@@ -1674,14 +1771,22 @@ static int launch_check(const char *what)
 
 static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
-                          double *best_cost, unsigned long long *n_evaluated, void *stream);
+                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream);
 
 extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
                           double *best_cost, void *stream)
 {
     return sl_plan_launch(batch, params, cost_map, index_map, path_idx, status, layers_done, best_cost, nullptr,
-                          stream);
+                          nullptr, stream);
+}
+
+extern "C" int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
+                                  int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
+                                  double *best_cost, int32_t *order_ws, void *stream)
+{
+    return sl_plan_launch(batch, params, cost_map, index_map, path_idx, status, layers_done, best_cost, nullptr,
+                          order_ws, stream);
 }
 
 extern "C" int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
@@ -1694,12 +1799,12 @@ extern "C" int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *
         return MP_E_UNSUPPORTED;
     }
     return sl_plan_launch(batch, params, nullptr, nullptr, path_idx, status, layers_done, best_cost,
-                          (unsigned long long *)n_evaluated, stream);
+                          (unsigned long long *)n_evaluated, nullptr, stream);
 }
 
 static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
-                          double *best_cost, unsigned long long *n_evaluated, void *stream)
+                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream)
 {
     int rc = check_batch(batch, params);
     if (rc) return rc;
@@ -1721,6 +1826,7 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.edge_cost = nullptr;
     a.pair_cap = 0;
     a.n_evaluated = n_evaluated;
+    a.order = nullptr;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
     // well (the two must agree bit for bit; used by the tests)
     const bool narrow_ok = mp_knob_sl_narrow() != 0;
@@ -1783,6 +1889,12 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     const bool maps = cost_map || index_map;
     const dim3 grid(batch->B), block(threads);
     hipStream_t st = (hipStream_t)stream;
+    if (order_ws && !n_evaluated && batch->B > 1) {
+        // heaviest scenarios first: weights -> order_ws[0..B), order -> order_ws[B..2B)
+        hipLaunchKernelGGL(sl_weight_kernel, dim3((batch->B + 3) / 4), dim3(4 * MP_WAVE), 0, st, a, order_ws);
+        hipLaunchKernelGGL(sl_order_kernel, dim3(1), dim3(1024), 0, st, batch->B, order_ws, order_ws + batch->B);
+        a.order = order_ws + batch->B;
+    }
     if (n_evaluated) {
         if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, false, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((sl_plan_kernel<false, false, true>), grid, block, lds, st, a);
@@ -1818,6 +1930,7 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     a.edge_cost = edge_cost;
     a.pair_cap = 0;
     a.n_evaluated = nullptr;
+    a.order = nullptr;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fill_i32_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, status, batch->B,
                        MP_SL_FOUND);

@@ -341,6 +341,42 @@ def test_sl_targets_that_no_edge_enters_without_a_collision(oracle, n_l):
     assert n_dead > 0
 
 
+def test_sl_heaviest_first_order_changes_nothing(oracle):
+    """mp_sl_plan_ordered launches the workgroups heaviest scenario first; outputs must be
+    those of mp_sl_plan bit for bit, also with per-scenario layer counts, scenarios without
+    obstacles and a dirty workspace."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(77)
+    B, n_s, n_l = 300, 9, 40
+    s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 1.5, 14, 0.2, 0.7, jitter=True)
+    ob_s, ob_l, n_ob = pad_obstacles(obs)
+    n_ob[::7] = 0
+    n_layers = rng.integers(0, n_s + 1, B).astype(np.int32)
+    sb = mb.SLBatch(s_map[:, :, 0], l_map, ego, ob_s, ob_l, n_ob, ob_dist, n_layers=n_layers)
+    prm = mb.sl_params(early_exit=True, n_l=n_l)
+    plain = mb.sl_plan(sb, prm, ordered=False)
+    out = mb.SLPlanOut(B, n_s, n_l)
+    out.order_ws.fill_(-12345)
+    ordered = mb.sl_plan(sb, prm, out)
+    torch.cuda.synchronize()
+    order = out.order_ws[B:].cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(B))                 # a permutation of the scenarios
+    key = out.order_ws[:B].cpu().numpy()
+    assert (np.diff(key[order]) <= 0).all() and key.max() > key.min()   # heaviest bin first
+    for k in ("cost_map", "index_map", "path_idx", "status", "layers_done"):
+        assert torch.equal(getattr(plain, k), getattr(ordered, k)), k
+    assert np.array_equal(plain.best_cost.cpu().numpy(), ordered.best_cost.cpu().numpy(), equal_nan=True)
+    b = int(order[0])                                                   # the scenario rated heaviest, against the oracle
+    if n_layers[b] > 0:
+        L = n_layers[b]
+        ref = oracle.sl_find_path(s_map[b, :L], l_map[b, :L], int((n_l - 1) / 2), ego[b], obs[b][: n_ob[b]], ob_dist[b])
+        got = dict(found=int(ordered.status[b]) == 1, cost_map=ordered.cost_map[b, :L].cpu().numpy(),
+                   index_map=ordered.index_map[b, :L].cpu().numpy(), path_idx=ordered.path_idx[b, :L].cpu().numpy(),
+                   layers_done=int(ordered.layers_done[b]))
+        assert_sl_parity(got, ref)
+
+
 def gpu_sl_nodes(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, n_layers=None):
     """Per-node edge kernel + DP kernel; returns (list of result dicts, edge tensor, edge status)."""
     import torch
