@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 122
+#define MP_VERSION 123
 
 /* host-side return codes */
 #define MP_OK 0
@@ -135,8 +135,8 @@ int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cos
  * entry and on return (weights in the first half, the order in the second); two
  * small launches in front of the kernel fill it.  The weight is a guess from the
  * obstacles near the first layers and decides nothing but the order: outputs
- * are those of mp_sl_plan, bit for bit.  Lattices of up to 16 lanes (their
- * kernel takes a wave or two per scenario) ignore the workspace. */
+ * are those of mp_sl_plan, bit for bit.  Lattices of up to 16 lanes, whose
+ * kernel prices every edge, are weighted by obstacles x layers. */
 int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                        int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
                        double *best_cost, int32_t *order_ws, void *stream);
@@ -195,6 +195,15 @@ int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const 
              const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
              double speed_lim, double ds, double dt, double *cost, int32_t *pre,
              int32_t *path_s_ind, int32_t *path_len, void *stream);
+
+/* mp_st_dp with the workgroups launched widest grid first, for batches whose
+ * scenarios differ in grid width (a plan's time follows n_s squared); order_ws
+ * as in mp_sl_plan_ordered (2*B int32 of device scratch).  No counterpart in
+ * the reference; outputs are those of mp_st_dp, bit for bit. */
+int mp_st_dp_ordered(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+             const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+             double speed_lim, double ds, double dt, double *cost, int32_t *pre,
+             int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream);
 
 /* Replaces STMap.add_obstacle + set_obstate (Planning/DP_Speed/st_map.py:24-60):
  * for each time layer and obstacle, the s of the first and last path point

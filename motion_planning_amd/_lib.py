@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
-MP_VERSION = 122   # MP_VERSION of include/mplattice.h this binding was written for
+MP_VERSION = 123   # MP_VERSION of include/mplattice.h this binding was written for
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
@@ -75,6 +75,7 @@ SIGNATURES = {
                               + [C.POINTER(SlParams)] + [_vp] * 3),
     "mp_sl_dp": (C.c_int, [C.c_int32] * 3 + [_vp, _vp, C.POINTER(SlParams)] + [_vp] * 7),
     "mp_st_dp": (C.c_int, [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp] + [C.c_double] * 3 + [_vp] * 5),
+    "mp_st_dp_ordered": (C.c_int, [C.c_int32] * 3 + [_vp] * 4 + [C.c_int32, _vp] + [C.c_double] * 3 + [_vp] * 6),
     "mp_st_regions": (C.c_int, [C.c_int32] * 2 + [_vp] * 3 + [C.c_int32] + [_vp] * 4 + [C.c_int32] + [_vp] * 4
                       + [C.c_int32] * 2 + [_vp] * 5),
     "mp_refline_tables": (C.c_int, [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_double, C.c_int32]

@@ -188,12 +188,15 @@ def sl_dp(edge_cost, params, out=None, n_layers=None):
     return out
 
 
-def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tables=True, n_s_max=None, out=None):
+def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tables=True, n_s_max=None, out=None,
+          ordered=False):
     """ST speed DP (replaces SpeedPlanner.find_speed, speed_planner.py:57-162).
 
     n_s [B]; s_down / s_up [B, n_t, r_max]; n_reg [B, n_t]; cur_vel [B].
     Returns dict(cost, pre, path_s_ind [B, n_t], path_len [B]); `out` (a dict returned by
-    an earlier call of the same shape) is written in place instead of allocating."""
+    an earlier call of the same shape) is written in place instead of allocating.
+    ordered=True launches the widest grids first (mp_st_dp_ordered; for batches whose grids
+    differ in width; same results)."""
     n_s = to_dev(n_s, torch.int32)
     n_reg = to_dev(n_reg, torch.int32)
     B, n_t = n_reg.shape
@@ -211,6 +214,14 @@ def st_dp(n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds=1.0, dt=0.5, want_tab
         pre = torch.empty((B, n_t, N), dtype=torch.int32, device=dev) if want_tables else None
         idx = torch.empty((B, n_t), dtype=torch.int32, device=dev)
         plen = torch.empty(B, dtype=torch.int32, device=dev)
+    if ordered:
+        ws = out.get("order_ws") if out is not None else None
+        if ws is None or ws.numel() < 2 * B:
+            ws = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        check(lib().mp_st_dp_ordered(B, n_t, N, _p(n_s), _p(s_down), _p(s_up), _p(n_reg), r_max, _p(cur_vel),
+                                     float(speed_lim), float(ds), float(dt), _p(cost), _p(pre), _p(idx), _p(plen),
+                                     _p(ws), _stream()), "mp_st_dp_ordered")
+        return dict(cost=cost, pre=pre, path_s_ind=idx, path_len=plen, order_ws=ws)
     check(lib().mp_st_dp(B, n_t, N, _p(n_s), _p(s_down), _p(s_up), _p(n_reg), r_max, _p(cur_vel),
                          float(speed_lim), float(ds), float(dt), _p(cost), _p(pre), _p(idx), _p(plen),
                          _stream()), "mp_st_dp")

@@ -206,6 +206,19 @@ __device__ __forceinline__ double arange_value(int k, int n, double t_st, double
     return __dadd_rn(t_st, __dmul_rn((double)k, delta));
 }
 
+// ---- order of the workgroups ----------------------------------------------------------
+
+// A scenario's guessed weight as one of 64 bins, quarter octaves (the kernels that plan
+// scenarios of very different length launch their workgroups by descending bin).
+#define MP_WEIGHT_BINS 64
+__device__ __forceinline__ int mp_weight_bin(double w)
+{
+    if (!(w >= 1.0)) return 0;
+    const int bin = (int)(4.0f * log2f((float)(w < 1e9 ? w : 1e9))) + 1;
+    return bin < MP_WEIGHT_BINS - 1 ? bin : MP_WEIGHT_BINS - 1;
+}
+void mp_order_launch(int B, const int32_t *key, int32_t *order, hipStream_t st);
+
 // ---- quintic pieces (Model/curve.py) -----------------------------------------
 
 // Model/curve.py:130-157 QuinticPoly coefficients.

@@ -107,7 +107,8 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(n_final, int32_t, MP_I32, d.B, 1, 1, 1)                                                \
     X(final_status, int32_t, MP_I32, d.B, 1, 1, 1)                                           \
     X(final_x, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
-    X(final_y, double, MP_F64, d.B, d.q_max, 1, 1)
+    X(final_y, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
+    X(order_ws, int32_t, MP_I32, d.B, 2, 1, 1)
 
 struct PlanPtrs {
 #define X(name, ctype, dt, d0, d1, d2, d3) ctype *name;
@@ -613,8 +614,9 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         sb.n_layers = o.n_layers;
         mp_sl_params sp = p.sl;
         sp.mid_l = mid_l;
-        rc = mp_sl_plan(&sb, &sp, o.cost_map, o.index_map, o.path_idx, o.sl_status, o.layers_done, o.best_cost,
-                        stream);
+        // (scenes differ in obstacles and layers by an order of magnitude: heaviest first)
+        rc = mp_sl_plan_ordered(&sb, &sp, o.cost_map, o.index_map, o.path_idx, o.sl_status, o.layers_done,
+                                o.best_cost, o.order_ws, stream);
         if (rc) return rc;
     }
     PLAN_STAGE_DONE();
@@ -639,8 +641,9 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
                                o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream);
     if (rc) return rc;
     PLAN_STAGE_DONE();
-    rc = mp_st_dp(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
-                  p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len, stream);
+    rc = mp_st_dp_ordered(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
+                          p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len,
+                          o.order_ws, stream);
     if (rc) return rc;
     PLAN_STAGE_DONE();
 

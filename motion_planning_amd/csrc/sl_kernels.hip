@@ -1092,8 +1092,8 @@ __global__ void sl_plan_kernel(SlDev a)
 // sl_weight_kernel: one wave per scenario, lanes over the obstacles.  For the pairs of the
 // first three walking layers, the number of source lanes the pair blocks for a target: the
 // sample sits at l1 + h0*(l2 - l1), so the blocked sources span 2*rho / |1 - h0| (rho: what
-// is left of the radius at the pair's arc-length gap).  The sum goes into one of 16 bins
-// (its binary logarithm).
+// is left of the radius at the pair's arc-length gap).  The sum goes into one of 64 bins
+// (quarter octaves).
 __global__ void sl_weight_kernel(SlDev a, int32_t *key)
 {
     const int lane = threadIdx.x & (MP_WAVE - 1);
@@ -1139,30 +1139,32 @@ __global__ void sl_weight_kernel(SlDev a, int32_t *key)
         }
     }
     for (int m = 32; m >= 1; m >>= 1) w += __shfl_xor(w, m, MP_WAVE);
-    if (lane == 0) {
-        int bin = 0;
-        if (w >= 1.0) {
-            const unsigned u = w < 1e9 ? (unsigned)w : 1000000000u;
-            bin = 32 - __builtin_clz(u);
-            bin = bin > 15 ? 15 : bin;
-        }
-        key[b] = bin;
-    }
+    if (lane == 0) key[b] = mp_weight_bin(w);
 }
 
-// sl_order_kernel: one workgroup; a counting sort of the scenarios by bin, heaviest bin
-// first (the order inside a bin is whatever the atomics give).
-__global__ void sl_order_kernel(int B, const int32_t *key, int32_t *order)
+// The same for lattices of up to 16 lanes, whose kernel prices every edge: a scenario's time
+// follows its (sample, obstacle) pairs, i.e. obstacles x layers.  One thread per scenario.
+__global__ void sl_weight_narrow_kernel(SlDev a, int32_t *key)
 {
-    __shared__ int cnt[16], base[16];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.in.B) return;
+    const int n_ob = min(max(a.in.n_ob[b], 0), a.in.ob_stride);
+    key[b] = mp_weight_bin((double)(n_ob + 1) * (double)scenario_layers(a.in, b));
+}
+
+// mp_order_kernel: one workgroup; a counting sort of the scenarios by bin (0..63), heaviest
+// bin first (the order inside a bin is whatever the atomics give).
+__global__ void mp_order_kernel(int B, const int32_t *key, int32_t *order)
+{
+    __shared__ int cnt[MP_WEIGHT_BINS], base[MP_WEIGHT_BINS];
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (tid < 16) cnt[tid] = 0;
+    if (tid < MP_WEIGHT_BINS) cnt[tid] = 0;
     __syncthreads();
-    for (int b = tid; b < B; b += nt) atomicAdd(&cnt[key[b] & 15], 1);
+    for (int b = tid; b < B; b += nt) atomicAdd(&cnt[key[b] & (MP_WEIGHT_BINS - 1)], 1);
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int k = 15; k >= 0; --k) {
+        for (int k = MP_WEIGHT_BINS - 1; k >= 0; --k) {
             base[k] = run;
             run += cnt[k];
             cnt[k] = 0;
@@ -1170,9 +1172,15 @@ __global__ void sl_order_kernel(int B, const int32_t *key, int32_t *order)
     }
     __syncthreads();
     for (int b = tid; b < B; b += nt) {
-        const int k = key[b] & 15;
+        const int k = key[b] & (MP_WEIGHT_BINS - 1);
         order[base[k] + atomicAdd(&cnt[k], 1)] = b;
     }
+}
+
+// order[0..B) = the scenarios by descending bin key[0..B) (for the other kernels of the library)
+void mp_order_launch(int B, const int32_t *key, int32_t *order, hipStream_t st)
+{
+    hipLaunchKernelGGL(mp_order_kernel, dim3(1), dim3(1024), 0, st, B, key, order);
 }
 
 // ---------------------------------------------------------------------------
@@ -1194,7 +1202,8 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
 {
     if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
     const int n_l = a.in.n_l, n_sm = a.in.n_s;
     const int n_s = scenario_layers(a.in, b);
@@ -1852,6 +1861,11 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
         if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: too many layers for LDS"); return MP_E_UNSUPPORTED; }
         const dim3 grid(batch->B), block(threads);
         hipStream_t st = (hipStream_t)stream;
+        if (order_ws && batch->B > 1) {
+            hipLaunchKernelGGL(sl_weight_narrow_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, a, order_ws);
+            mp_order_launch(batch->B, order_ws, order_ws + batch->B, st);
+            a.order = order_ws + batch->B;
+        }
         const bool nmaps = cost_map || index_map;
 #define SLN_LAUNCH(WW)                                                                              \
     if (nmaps) hipLaunchKernelGGL((sl_plan_narrow_kernel<WW, true>), grid, block, lds, st, a);      \
@@ -1892,7 +1906,7 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     if (order_ws && !n_evaluated && batch->B > 1) {
         // heaviest scenarios first: weights -> order_ws[0..B), order -> order_ws[B..2B)
         hipLaunchKernelGGL(sl_weight_kernel, dim3((batch->B + 3) / 4), dim3(4 * MP_WAVE), 0, st, a, order_ws);
-        hipLaunchKernelGGL(sl_order_kernel, dim3(1), dim3(1024), 0, st, batch->B, order_ws, order_ws + batch->B);
+        mp_order_launch(batch->B, order_ws, order_ws + batch->B, st);
         a.order = order_ws + batch->B;
     }
     if (n_evaluated) {

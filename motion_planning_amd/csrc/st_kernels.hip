@@ -27,6 +27,7 @@ struct StDev {
     double *cost;
     int32_t *pre;
     int32_t *path_s_ind, *path_len;
+    const int32_t *order; // workgroup i plans scenario order[i] (null: scenario i)
 };
 
 // Blocked intervals of one time layer as seen from one cell (arc length s).
@@ -247,10 +248,11 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // (every record's quiet word and flag word were reset before the barrier in front of this call)
     const double front_step = sh.front(n_s > 1 ? 1 : 0);
     const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
-    // q / n_s by multiplication: exact while q * n_s < 2^32 (q < 8 * n_s, n_s <= 1024)
-    const unsigned n_s_magic = 0xffffffffu / (unsigned)n_s + 1u;
+    // q / n_s by multiplication: exact while q * n_s < 2^32 (q < 8 * n_s, n_s <= 1024); a
+    // single-cell grid has no 32-bit multiplier and needs none
+    const unsigned n_s_magic = n_s > 1 ? 0xffffffffu / (unsigned)n_s + 1u : 0u;
     for (int q = tid; q < n_s * RT; q += nt) {
-        const int k = (int)__umulhi((unsigned)q, n_s_magic), j = q - k * n_s;
+        const int k = n_s > 1 ? (int)__umulhi((unsigned)q, n_s_magic) : q, j = q - k * n_s;
         double *rec = tb.cell(j);
         double dnk = MP_INF, ck = 0.0; // slots beyond the layer's intervals never fire and add exact zeros
         unsigned e_fire = 0xffffu;
@@ -387,7 +389,8 @@ __device__ __forceinline__ void st_dp_body(StDev a)
 {
     if (!TABLES) a.cost = nullptr, a.pre = nullptr;
     extern __shared__ double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int N = a.n_s_max, n_t = a.n_t, R_max = a.r_max;
     const int n_s = a.n_s[b];
     if (n_s <= 0 || n_s > N) { // no grid for this scenario: no path
@@ -858,6 +861,18 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
     if (tid == 0) a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
 }
 
+// A plan's time follows the square of its grid width (and its intervals): one thread per
+// scenario bins that, for batches whose grids differ (mp_st_dp_ordered).
+__global__ void st_weight_kernel(int B, int n_t, const int32_t *n_s, const int32_t *n_reg, int32_t *key)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double n = (double)max(n_s[b], 0);
+    int regs = 0;
+    for (int i = 1; i < n_t; ++i) regs += max(n_reg[(size_t)b * n_t + i], 0);
+    key[b] = mp_weight_bin(n * n * (4.0 + (double)regs / (double)(n_t - 1)));
+}
+
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
@@ -871,10 +886,33 @@ static int st_launch_check(const char *what)
     return MP_OK;
 }
 
+static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+                        const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+                        double speed_lim, double ds, double dt, double *cost, int32_t *pre,
+                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream);
+
 extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
                         const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
                         double speed_lim, double ds, double dt, double *cost, int32_t *pre,
                         int32_t *path_s_ind, int32_t *path_len, void *stream)
+{
+    return st_dp_launch(B, n_t, n_s_max, n_s, s_down, s_up, n_reg, r_max, cur_vel, speed_lim, ds, dt, cost, pre,
+                        path_s_ind, path_len, nullptr, stream);
+}
+
+extern "C" int mp_st_dp_ordered(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+                                const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+                                double speed_lim, double ds, double dt, double *cost, int32_t *pre,
+                                int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream)
+{
+    return st_dp_launch(B, n_t, n_s_max, n_s, s_down, s_up, n_reg, r_max, cur_vel, speed_lim, ds, dt, cost, pre,
+                        path_s_ind, path_len, order_ws, stream);
+}
+
+static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+                        const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+                        double speed_lim, double ds, double dt, double *cost, int32_t *pre,
+                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream)
 {
     if (B <= 0 || n_t < 2 || n_s_max <= 0 || r_max < 0) { mp_set_error("bad B/n_t/n_s_max/r_max"); return MP_E_BADARG; }
     if (!n_s || !n_reg || !cur_vel || !path_s_ind || !path_len || (r_max > 0 && (!s_down || !s_up))) {
@@ -891,7 +929,7 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     if (r_tab > 8 || r_tab == 7) r_tab = 8; // the split path keeps a cell's intervals in registers (7 run as 8)
     while (r_tab > 0 && st_tab_bytes(n_s_max, r_tab) > 40 * 1024) --r_tab;
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, st_lanes_per_cell(B, n_s_max), n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
-            pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len};
+            pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // wide grid gets more lanes per layer
@@ -901,6 +939,12 @@ extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
+    if (order_ws && B > 1) {
+        // widest grids first: weights -> order_ws[0..B), order -> order_ws[B..2B)
+        hipLaunchKernelGGL(st_weight_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_t, n_s, n_reg, order_ws);
+        mp_order_launch(B, order_ws, order_ws + B, st);
+        a.order = order_ws + B;
+    }
     // batches with few intervals per layer (r_max is the caller's bound) take the instance
     // built for that bound; MP_ST_GENERIC=1 keeps them on the kernel that holds every path
     // large batches with few intervals per layer (r_max is the caller's bound) take the

@@ -118,6 +118,63 @@ def test_st_large_batch_instances_match_the_general_kernel(oracle, n_s_hi, r_max
         same(tab["cost"][b, :, :n_s[b]].cpu().numpy(), ref["cost"], "cost[%d]" % b)
 
 
+@pytest.mark.parametrize("B", [256, 2048])
+def test_st_grids_of_one_to_three_cells(oracle, B):
+    """The narrowest grids (a path shorter than 3 m), with intervals far beyond them: every
+    interval slot of their cells must be classified (a stale slot would add whatever LDS held)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(B + 1)
+    n_t, N, r_max = 11, 90, 5
+    n_s = rng.integers(1, 4, B).astype(np.int32)
+    n_s[-1] = N
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(0, N, (B, n_t, r_max))
+    up = down + rng.uniform(0, 8, (B, n_t, r_max))
+    cur = rng.uniform(0, 10, B)
+    for rep in range(3):
+        lean = mb.st_dp(n_s, down, up, n_reg, cur, LIM, want_tables=False, n_s_max=N)
+        tab = mb.st_dp(n_s, down, up, n_reg, cur, LIM, want_tables=True, n_s_max=N)
+        torch.cuda.synchronize()
+        assert torch.equal(lean["path_s_ind"], tab["path_s_ind"]) and torch.equal(lean["path_len"], tab["path_len"])
+        cost = tab["cost"].cpu().numpy()
+        for b in range(0, B, max(1, B // 128)):
+            ref = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), LIM)
+            same(cost[b, :, :n_s[b]], ref["cost"], "cost[%d]" % b)
+            plen = int(lean["path_len"][b])
+            assert np.array_equal(lean["path_s_ind"][b, :plen].cpu().numpy(), ref["path_s_ind"]), b
+
+
+@pytest.mark.parametrize("B", [300, 2500])
+def test_st_widest_first_order_changes_nothing(B):
+    """mp_st_dp_ordered launches the workgroups widest grid first; paths and tables must be
+    those of mp_st_dp bit for bit (scenarios without a grid included)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(B)
+    n_t, N, r_max = 11, 90, 4
+    n_s = rng.integers(0, N + 1, B).astype(np.int32)
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(0, N, (B, n_t, r_max))
+    up = down + rng.uniform(0, 8, (B, n_t, r_max))
+    cur = rng.uniform(0, 10, B)
+    tables = B < 2048
+    plain = mb.st_dp(n_s, down, up, n_reg, cur, LIM, want_tables=tables, n_s_max=N)
+    ordered = mb.st_dp(n_s, down, up, n_reg, cur, LIM, want_tables=tables, n_s_max=N, ordered=True)
+    torch.cuda.synchronize()
+    order = ordered["order_ws"][B:].cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(B))
+    key = ordered["order_ws"][:B].cpu().numpy()
+    assert (np.diff(key[order]) <= 0).all() and key.max() > key.min()     # heaviest bin first
+    assert n_s[order[:20]].mean() > n_s[order[-20:]].mean()
+    for k in ("path_s_ind", "path_len"):
+        assert torch.equal(plain[k], ordered[k]), k
+    if tables:      # (a scenario without a grid leaves its table rows unwritten)
+        live = torch.as_tensor(n_s > 0, device=plain["cost"].device)
+        for k in ("cost", "pre"):
+            assert torch.equal(plain[k][live], ordered[k][live]), k
+
+
 @pytest.mark.parametrize("n_s_hi,B,r_max", [(150, 10, 12), (600, 3, 6), (1024, 2, 4)])
 def test_st_many_intervals_and_wide_grids(oracle, n_s_hi, B, r_max):
     """More than 8 intervals on a layer, and grids too wide for the per-cell
