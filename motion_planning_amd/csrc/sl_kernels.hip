@@ -513,6 +513,18 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     // penalty (a lower bound of its cost, since the penalty only adds and rounding is
     // monotone) and its pairs are only looked at if that bound could still win.
     auto consider = [&](int j, double l1, double cp, double dl) {
+        bool hit = false;
+        if constexpr (!BOUND_FIRST) {
+            // the collision test first: a candidate that hits pays the penalty, and where its
+            // own cost plus the penalty already leaves no room (a blocked target walking along
+            // a blocked stretch of sources) the closed form is not needed
+            hit = col.hit(l1, dl);
+            if (hit && w_inv > 0.0) {
+                double gap = (best - cp) - pen * (1.0 - 1e-12);
+                gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
+                if (dl * dl > gap * w_inv) return;
+            }
+        }
         if constexpr (COUNT) ++*n_eval;
         const double u = l1 - src.mid;
         const double e = edge_closed_form(dl, guide_straight(u, src.K, src.w_d, src.d_s), src.two_cga * u, Q);
@@ -522,7 +534,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (!(c < best || (c == best && j < bj))) return; // lower index wins ties
             if (col.hit(l1, dl)) c = (e + pen) + cp;
         } else {
-            c = (e + (col.hit(l1, dl) ? pen : 0.0)) + cp;
+            c = (e + (hit ? pen : 0.0)) + cp;
         }
         if (!(c < best || (c == best && j < bj))) return;
         best = c;
