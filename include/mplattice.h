@@ -27,6 +27,7 @@
  * store), MP_ST_REGIONS_ONCE=0 (per-layer scans in mp_st_regions),
  * MP_ST_GENERIC=1 (mp_st_dp through the kernel that holds every relaxation path
  * instead of the instance built for the batch's interval bound r_max),
+ * MP_ORDER=0 (the *_ordered entry points launch in the caller's order),
  * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n (workgroup size of
  * mp_st_dp / mp_refline_tables / the front end of mp_plan_scenes; honoured only
  * when a multiple of 64 within 64..1024).
@@ -134,7 +135,9 @@ int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cos
  * start last.  order_ws: 2*B int32 of device scratch, contents irrelevant on
  * entry and on return (weights in the first half, the order in the second); two
  * small launches in front of the kernel fill it.  The weight is a guess from the
- * obstacles near the first layers and decides nothing but the order: outputs
+ * obstacles near the first layers and decides nothing but the order (batches
+ * of up to 1536 scenarios, which fit on the chip at once, are launched as they
+ * come and the workspace is not touched): outputs
  * are those of mp_sl_plan, bit for bit.  Lattices of up to 16 lanes, whose
  * kernel prices every edge, are weighted by obstacles x layers. */
 int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,

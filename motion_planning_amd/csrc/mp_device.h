@@ -17,6 +17,7 @@ int mp_knob_st_threads();
 int mp_knob_rl_threads();
 int mp_knob_fe_threads();
 int mp_knob_st_generic();
+int mp_knob_order(); // 0: the *_ordered entry points launch in the caller's order
 #define MP_INF (__builtin_huge_val())
 
 // ---- wave-level reductions (64 lanes) ---------------------------------------
@@ -211,6 +212,9 @@ __device__ __forceinline__ double arange_value(int k, int n, double t_st, double
 // A scenario's guessed weight as one of 64 bins, quarter octaves (the kernels that plan
 // scenarios of very different length launch their workgroups by descending bin).
 #define MP_WEIGHT_BINS 64
+// A batch that fits on the chip at once (6-8 workgroups on each of 256 CUs) gains nothing
+// from an order: every workgroup starts at the launch.
+#define MP_ORDER_MIN_BATCH 1536
 __device__ __forceinline__ int mp_weight_bin(double w)
 {
     if (!(w >= 1.0)) return 0;

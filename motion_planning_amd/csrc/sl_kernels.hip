@@ -1873,7 +1873,7 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
         if (lds > 64 * 1024) { mp_set_error("mp_sl_plan: too many layers for LDS"); return MP_E_UNSUPPORTED; }
         const dim3 grid(batch->B), block(threads);
         hipStream_t st = (hipStream_t)stream;
-        if (order_ws && batch->B > 1) {
+        if (order_ws && batch->B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
             hipLaunchKernelGGL(sl_weight_narrow_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, a, order_ws);
             mp_order_launch(batch->B, order_ws, order_ws + batch->B, st);
             a.order = order_ws + batch->B;
@@ -1915,7 +1915,7 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     const bool maps = cost_map || index_map;
     const dim3 grid(batch->B), block(threads);
     hipStream_t st = (hipStream_t)stream;
-    if (order_ws && !n_evaluated && batch->B > 1) {
+    if (order_ws && !n_evaluated && batch->B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
         // heaviest scenarios first: weights -> order_ws[0..B), order -> order_ws[B..2B)
         hipLaunchKernelGGL(sl_weight_kernel, dim3((batch->B + 3) / 4), dim3(4 * MP_WAVE), 0, st, a, order_ws);
         mp_order_launch(batch->B, order_ws, order_ws + batch->B, st);

@@ -939,7 +939,7 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
-    if (order_ws && B > 1) {
+    if (order_ws && B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
         // widest grids first: weights -> order_ws[0..B), order -> order_ws[B..2B)
         hipLaunchKernelGGL(st_weight_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_t, n_s, n_reg, order_ws);
         mp_order_launch(B, order_ws, order_ws + B, st);

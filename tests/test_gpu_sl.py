@@ -341,14 +341,14 @@ def test_sl_targets_that_no_edge_enters_without_a_collision(oracle, n_l):
     assert n_dead > 0
 
 
-def test_sl_heaviest_first_order_changes_nothing(oracle):
+def test_sl_heaviest_first_order_changes_nothing(oracle, knob):
     """mp_sl_plan_ordered launches the workgroups heaviest scenario first; outputs must be
     those of mp_sl_plan bit for bit, also with per-scenario layer counts, scenarios without
     obstacles and a dirty workspace."""
     import torch
     from motion_planning_amd import batch as mb
     rng = np.random.default_rng(77)
-    B, n_s, n_l = 300, 9, 40
+    B, n_s, n_l = 1700, 9, 40        # (batches that fit on the chip at once are not ordered)
     s_map, l_map, ego, obs, ob_dist = random_batch(rng, B, n_s, n_l, 1.5, 14, 0.2, 0.7, jitter=True)
     ob_s, ob_l, n_ob = pad_obstacles(obs)
     n_ob[::7] = 0
@@ -375,6 +375,18 @@ def test_sl_heaviest_first_order_changes_nothing(oracle):
                    index_map=ordered.index_map[b, :L].cpu().numpy(), path_idx=ordered.path_idx[b, :L].cpu().numpy(),
                    layers_done=int(ordered.layers_done[b]))
         assert_sl_parity(got, ref)
+    # a batch that fits on the chip at once is launched as it comes, and so is any batch with the knob off
+    small = mb.SLBatch(s_map[:64, :, 0], l_map[:64], ego[:64], ob_s[:64], ob_l[:64], n_ob[:64], ob_dist[:64],
+                       n_layers=n_layers[:64])
+    out_s = mb.SLPlanOut(64, n_s, n_l)
+    out_s.order_ws.fill_(-12345)
+    mb.sl_plan(small, prm, out_s)
+    knob("MP_ORDER", 0)
+    out.order_ws.fill_(-12345)
+    off = mb.sl_plan(sb, prm, out)
+    torch.cuda.synchronize()
+    assert (out_s.order_ws == -12345).all() and (out.order_ws == -12345).all()
+    assert torch.equal(off.path_idx, plain.path_idx) and torch.equal(out_s.path_idx, plain.path_idx[:64])
 
 
 def gpu_sl_nodes(s_map, l_map, mid_l, ego, obs, ob_dist, early_exit=True, n_layers=None):
