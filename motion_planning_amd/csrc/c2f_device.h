@@ -59,6 +59,107 @@ __device__ __forceinline__ int c2f_nearest(const double *tx, const double *ty, i
     return k;
 }
 
+// Blocks of 2^bsh consecutive samples, at most 64 of them, for c2f_nearest_boxes.
+__host__ __device__ __forceinline__ int c2f_block_shift(int M)
+{
+    int bsh = 3;
+    while (((M + (1 << bsh) - 1) >> bsh) > 64) ++bsh;
+    return bsh;
+}
+
+// The same nearest sample as c2f_nearest for callers that convert many points against one
+// line and hold, per block of 2^bsh samples, the smallest and the largest ordinate
+// (ylo[b], yhi[b]; the abscissae ascend, so a block's first and last sample bound them).
+// A point d metres from the line makes c2f_nearest look at every sample within d of its
+// abscissa, 4 d / d_x of them; here
+//   1. one sample per block inside that range gives an upper bound mb of the smallest
+//      squared distance,
+//   2. a block is kept only if its bounding box comes within mb: the squared distance to
+//      the box, built with the same roundings as a sample's, never exceeds that of a sample
+//      inside (differences, squares and the sum are monotone),
+//   3. the samples of the kept blocks are compared, the block of the bound first, and a
+//      block is dropped if its box has fallen outside the minimum found meanwhile.
+// Step 3 also keeps the runner-up n2.  The reference takes the first minimum of the rounded
+// roots; if the runner-up's root differs from the minimum's, every other sample's is larger
+// still and the minimum's index is the answer whatever the order of the comparisons.  If it
+// does not (two samples at the same rounded distance) the point is given to c2f_nearest.
+__device__ __forceinline__ int c2f_nearest_boxes(const double *tx, const double *ty, const double *ylo,
+                                                 const double *yhi, int bsh, int M, double x, double y,
+                                                 double *dist_out)
+{
+    const int bs = 1 << bsh, nb = (M + bs - 1) >> bsh;
+    int i0 = 0;
+    if (M > 1) {
+        const double q = (x - tx[0]) / (tx[1] - tx[0]);
+        i0 = q > 0.0 ? (q < (double)(M - 1) ? (int)q : M - 1) : 0;
+    }
+    const int b0 = i0 >> bsh;
+    auto dist2 = [&](int i) {
+        const double dx = tx[i] - x, dy = ty[i] - y;
+        return dx * dx + dy * dy;
+    };
+    // squared distance to the box of block b; *gx2 = its part along x
+    auto box2 = [&](int b, double *gx2) {
+        const int first = b << bsh, last = min(first + bs, M) - 1;
+        const double xa = tx[first] - x, xb = tx[last] - x;     // xa <= xb
+        const double ya = ylo[b] - y, yb = yhi[b] - y;           // ya <= yb
+        const double gx = xa > 0.0 ? xa : (xb < 0.0 ? xb : 0.0);
+        const double gy = ya > 0.0 ? ya : (yb < 0.0 ? yb : 0.0);
+        *gx2 = gx * gx;
+        return *gx2 + gy * gy;
+    };
+    // 1. (a block wholly on one side of x, further away along x than the bound, ends the
+    //    walk on that side: the blocks behind it are further still)
+    double mb = dist2(i0);
+    int bb = b0;
+    int b_lo = b0, b_hi = b0; // the blocks looked at
+    for (int b = b0 - 1; b >= 0; --b) {
+        const double dxe = tx[(b << bsh) + bs - 1] - x;
+        if (dxe < 0.0 && dxe * dxe > mb * (1.0 + 1e-12)) break;
+        b_lo = b;
+        const double d2 = dist2((b << bsh) + (bs >> 1));
+        if (d2 < mb) { mb = d2; bb = b; }
+    }
+    for (int b = b0 + 1; b < nb; ++b) {
+        const double dxe = tx[b << bsh] - x;
+        if (dxe > 0.0 && dxe * dxe > mb * (1.0 + 1e-12)) break;
+        b_hi = b;
+        const double d2 = dist2(min((b << bsh) + (bs >> 1), M - 1));
+        if (d2 < mb) { mb = d2; bb = b; }
+    }
+    // 2.
+    const double thr = mb * (1.0 + 1e-12);
+    unsigned long long keep = 0ull;
+    for (int b = b_lo; b <= b_hi; ++b) {
+        double gx2;
+        if (b != bb && box2(b, &gx2) <= thr) keep |= 1ull << b;
+    }
+    // 3.
+    double m2 = MP_INF, n2 = MP_INF;
+    int k = 0;
+    auto block = [&](int b) {
+        const int first = b << bsh, end = min(first + bs, M);
+        for (int i = first; i < end; ++i) {
+            const double d2 = dist2(i);
+            const double hi = d2 > m2 ? d2 : m2;
+            n2 = hi < n2 ? hi : n2;
+            if (d2 < m2) { m2 = d2; k = i; }
+        }
+    };
+    block(bb);
+    while (keep) {
+        const int b = __ffsll((long long)keep) - 1;
+        keep &= keep - 1ull;
+        double gx2;
+        if (box2(b, &gx2) <= m2 * (1.0 + 1e-12)) block(b);
+    }
+    const double best = __dsqrt_rn(m2);
+    const bool tie = n2 <= m2 * (1.0 + 1e-12) && __dsqrt_rn(n2) == best;
+    *dist_out = best;
+    if (tie) k = c2f_nearest(tx, ty, M, x, y, dist_out);
+    return k;
+}
+
 // The whole conversion of one point; (cth, sth) = cos and sin of the heading at the
 // nearest sample.
 __device__ __forceinline__ void c2f_finish(const double *tx, const double *ty, const double *ts, int k,
@@ -84,13 +185,15 @@ __device__ __forceinline__ int c2f_point(const double *tx, const double *ty, con
 
 // The same with cos / sin of every sample's heading tabulated by the caller (cos_t[k] =
 // cos(tth[k]), sin_t[k] = sin(tth[k]): the same functions on the same arguments, so the
-// same bits), for kernels that convert many points against one line.
+// same bits), for kernels that convert many points against one line.  With block bounds
+// (ylo != nullptr, see c2f_nearest_boxes) the nearest sample is found through them.
 __device__ __forceinline__ int c2f_point_tab(const double *tx, const double *ty, const double *ts,
                                              const double *cos_t, const double *sin_t, int M, double x,
-                                             double y, double *s_out, double *l_out)
+                                             double y, double *s_out, double *l_out,
+                                             const double *ylo = nullptr, const double *yhi = nullptr, int bsh = 0)
 {
     double best;
-    const int k = c2f_nearest(tx, ty, M, x, y, &best);
+    const int k = ylo ? c2f_nearest_boxes(tx, ty, ylo, yhi, bsh, M, x, y, &best) : c2f_nearest(tx, ty, M, x, y, &best);
     c2f_finish(tx, ty, ts, k, best, cos_t[k], sin_t[k], x, y, s_out, l_out);
     return k;
 }

@@ -264,6 +264,8 @@ __global__ void plan_frontend_kernel(FrontDev a)
         return;
     }
     double *tx = smem, *ty = smem + m_max, *cos_t = smem + 2 * m_max, *sin_t = smem + 3 * m_max;
+    double *ylo = smem + 4 * m_max, *yhi = ylo + 64; // per block of samples, see c2f_nearest_boxes
+    const int bsh = c2f_block_shift(M);
     const size_t tb = (size_t)b * m_max;
     for (int k = tid; k < M; k += nt) {
         tx[k] = a.o.tab_x[tb + k];
@@ -275,6 +277,17 @@ __global__ void plan_frontend_kernel(FrontDev a)
         sin_t[k] = sin(th);
     }
     if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int q = tid; q < ((M + (1 << bsh) - 1) >> bsh); q += nt) {
+        const int first = q << bsh, end = min(first + (1 << bsh), M);
+        double lo = ty[first], hi = lo;
+        for (int k = first + 1; k < end; ++k) {
+            lo = ty[k] < lo ? ty[k] : lo;
+            hi = ty[k] > hi ? ty[k] : hi;
+        }
+        ylo[q] = lo;
+        yhi[q] = hi;
+    }
     __syncthreads();
     const double *ts = a.o.tab_s + tb, *tth = a.o.tab_theta + tb;
 
@@ -330,7 +343,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
                     y = a.in.dy_pos[2 * (q * F + f) + 1];
                     rad = a.in.dy_rad[q];
                 }
-                c2f_point_tab(tx, ty, ts, cos_t, sin_t, M, x, y, &s, &l);
+                c2f_point_tab(tx, ty, ts, cos_t, sin_t, M, x, y, &s, &l, ylo, yhi, bsh);
                 keep = fabs(l) - rad < a.l_width; // check_in_line (sl_map.py:111-112)
                 if (keep) r_loc = rad > r_loc ? rad : r_loc;
             }
@@ -575,7 +588,7 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         f.l_start = 0.0 - (p.l_width - p.save_width) / 2.0; // sl_map.py:71-72
         f.l_stop = 0.0 + (p.l_width - p.save_width) / 2.0;
         f.l_step = d.n_l > 1 ? (f.l_stop - f.l_start) / (double)(d.n_l - 1) : 0.0;
-        const size_t lds = (size_t)4 * d.m_max * sizeof(double);
+        const size_t lds = ((size_t)4 * d.m_max + 128) * sizeof(double); // tables + block bounds
         if (lds > 64 * 1024) { mp_set_error("m_max too large"); return MP_E_UNSUPPORTED; }
         const int n_slot = d.n_st_max + d.n_dy_max * d.n_frames;
         int threads = n_slot <= 64 ? 64 : (n_slot <= 128 ? 128 : 256);

@@ -167,6 +167,62 @@ def test_pipeline_random_vs_oracle(oracle, n_l):
     print("pipeline: %d of %d scenes found" % (n_found, len(scenes)))
 
 
+@pytest.mark.parametrize("line", ["straight", "curved", "steep"])
+def test_front_end_projection_equals_the_sample_walk(oracle, line):
+    """The chain's front end finds an obstacle's nearest reference-line sample through
+    bounding boxes of sample blocks; mp_c2f_batch walks the samples one by one.  Same
+    tables, same points: the same bits, also where two samples are equally far (points
+    above the middle between two samples of a straight line), for points far from the
+    line, before its start and behind its end."""
+    import torch
+    from motion_planning_amd import batch as mb
+    from motion_planning_amd import pipeline as pl
+    rng = np.random.default_rng({"straight": 1, "curved": 2, "steep": 3}[line])
+    c = {"straight": 0.0, "curved": 0.004, "steep": -0.011}[line]
+    scenes = []
+    for b in range(6):
+        nk = 14 + b
+        xs = -2.0 + 4.5 * np.arange(nk)
+        n_st, n_dy = 300, 20
+        st_x = rng.uniform(-12.0, xs[-1] + 12.0, n_st)
+        st_y = c * st_x * st_x + rng.uniform(-45.0, 45.0, n_st) * rng.choice([1.0, 0.2, 0.01], n_st)
+        # exactly above / below the middle between two samples, and on samples
+        st_x[:120] = -2.0 + 0.25 * rng.integers(0, 4 * int(xs[-1]), 120)
+        if line == "straight":
+            st_y[:40] = rng.choice([-3.0, -0.5, 0.0, 0.75, 6.0], 40)
+        dy0 = np.stack([rng.uniform(0, xs[-1], n_dy), rng.uniform(-20, 20, n_dy)], 1)
+        vel = np.stack([rng.uniform(-6, 6, n_dy), rng.uniform(-2, 2, n_dy)], 1)
+        frames = [dy0]
+        for _ in range(10):
+            frames.append(frames[-1] + vel * 0.5)
+        scenes.append(dict(rx=xs, ry=c * xs * xs, ego_vel=np.array([5.0, 0.0]), st_pos=np.stack([st_x, st_y], 1),
+                           st_rad=np.full(n_st, 0.8), dy_pos=np.stack(frames, 1), dy_rad=np.full(n_dy, 0.8)))
+    packed = pack_scenes(scenes)
+    r = pl.plan_batch(**packed)
+    torch.cuda.synchronize()
+    ok = (r["rl_status"].cpu().numpy() == 1) & (r["status"].cpu().numpy() != pl.PIPE_MAP_TOO_BIG)
+    assert ok.sum() >= 3
+    B = len(scenes)
+    n_st, n_dy = packed["st_pos"].shape[1], packed["dy_pos"].shape[1]
+    scn_st = np.repeat(np.arange(B, dtype=np.int32), n_st)
+    s, l = mb.c2f(r["tables"], packed["st_pos"][..., 0], packed["st_pos"][..., 1], scn_st)
+    scn_dy = np.repeat(np.arange(B, dtype=np.int32), n_dy * 11)
+    sd, ld = mb.c2f(r["tables"], packed["dy_pos"][..., 0], packed["dy_pos"][..., 1], scn_dy)
+    torch.cuda.synchronize()
+    for b in np.nonzero(ok)[0]:
+        assert torch.equal(r["st_s"][b, :n_st], s.reshape(B, n_st)[b])
+        assert torch.equal(r["st_l"][b, :n_st], l.reshape(B, n_st)[b])
+        assert torch.equal(r["dy_s"][b].reshape(-1)[:n_dy * 11], sd.reshape(B, -1)[b])
+        assert torch.equal(r["dy_l"][b].reshape(-1)[:n_dy * 11], ld.reshape(B, -1)[b])
+    # and the oracle's conversion of a sample of the points of one scene
+    b = int(np.nonzero(ok)[0][0])
+    sc = scenes[b]
+    conv = oracle.CartesianFrenetConverter(0.0, 0.0, sc["rx"], sc["ry"], 0.0)
+    for k in list(range(0, 120, 7)) + list(range(120, 300, 11)):
+        ws, wl = conv.cartesian_to_frenet(sc["st_pos"][k, 0], sc["st_pos"][k, 1])
+        close([float(r["st_s"][b, k]), float(r["st_l"][b, k])], [ws, wl])
+
+
 def test_pipeline_map_too_big_is_a_status():
     import torch
     from motion_planning_amd import pipeline as pl
