@@ -142,6 +142,7 @@ __global__ void refline_tables_kernel(RlDev a)
     __shared__ double Tseq[RL_SEG_CAP];         // running sums of T in segment order
     __shared__ double Scum[RL_SEG_CAP];         // running end of the current segment in calc_point_arr's walk
     __shared__ double arc_pre[RL_SEG_CAP + 1];  // arc length from the origin to the start of a segment
+    __shared__ double arc0[RL_ARC_CAP];         // integrand values of the origin's piece
     __shared__ double red_c[16];
     __shared__ int red_i[16];
     __shared__ double sc_d[8]; // t_max, delta, first piece, s_end
@@ -196,6 +197,7 @@ __global__ void refline_tables_kernel(RlDev a)
         for (int q = 0; q < n; ++q) {
             run += T[q];
             Tseq[q] = run;
+            Scum[q] = run; // the walk's running ends when it starts in segment 0 (else redone below)
             if (!(T[q] > 0.0)) ascending = false;
             if (q >= 1 && !(T[q] > dt * (1.0 + 1e-9))) long_segs = false;
         }
@@ -215,7 +217,9 @@ __global__ void refline_tables_kernel(RlDev a)
             double tt;
             curve_get_i(T, n, (0.0 + t_bios) - t_bios, &i0, &tt);
             double t_sum = np_sum_gen(i0 + 1, [&](int q) { return T[q]; });
-            if (parallel_walk) {
+            if (parallel_walk && i0 == 0) {
+                // Scum already holds these very additions
+            } else if (parallel_walk) {
                 Scum[i0] = t_sum;
                 for (int q = i0 + 1; q < n; ++q) { t_sum += T[q]; Scum[q] = t_sum; }
             } else {
@@ -303,11 +307,21 @@ __global__ void refline_tables_kernel(RlDev a)
     double st_t;
     curve_get_i_tab(Tseq, T, n, ascending, t0, &st_i, &st_t);
     for (int i = tid; i < n; i += nt) seg_full[i] = quintic_arc_len(coef + 6 * i, 0, T[i], dt, &bad, ftab + RL_FT * i);
+    // the origin's segment from st_t to its end (quintic_arc_len's sum): the integrand values
+    // by as many lanes, added up by one in that function's order
+    int n0;
+    double delta0;
+    const int K0 = arange_count(st_t, T[st_i], dt, RL_ARC_CAP, &n0, &delta0);
+    if (K0 < 0) bad = 1;
+    for (int q = tid; q < K0; q += nt) {
+        const double d = quintic_eval(coef + 6 * st_i, arange_value(q, n0, st_t, T[st_i], dt, delta0), 1);
+        arc0[q] = __dsqrt_rn(1 + d * d);
+    }
     __syncthreads();
     if (tid == 0) {
         // arc length up to the start of every later segment, in calc_arc_len's order:
         // the origin's segment from st_t to its end, then the full segments one by one
-        double arc = quintic_arc_len(coef + 6 * st_i, st_t, T[st_i], dt, &bad);
+        double arc = K0 > 0 ? 1 * dt * np_sum_gen(K0, [&](int q) { return arc0[q]; }) : 0.0;
         for (int e = st_i + 1; e < n; ++e) {
             arc_pre[e] = arc;
             arc += seg_full[e];
@@ -320,8 +334,9 @@ __global__ void refline_tables_kernel(RlDev a)
         tab_s[k] = arc_from_origin(ac, x - t_bios, &bad);
     }
     // get_s of the last knot: the length SLMap lays its layers along (sl_map.py:52)
+    // (by the last lane: the first wave carries every single-lane step above)
     const double rx_max = kx[n];
-    if (tid == 0)
+    if (tid == nt - 1)
         sc_d[3] = arc_from_origin(ac, rx_max - t_bios, &bad);
     // Frenet->Cartesian table (cfc.py:55-60, 72-86): abscissae
     // get_arange(rx_ori, rx_max, d_x) with their arc length, ordinate and heading
