@@ -284,7 +284,10 @@ __global__ void refline_tables_kernel(RlDev a)
         const double dl = quintic_eval(coef + 6 * ii, tt, 1);
         const double ddl = quintic_eval(coef + 6 * ii, tt, 2);
         tab_th[k] = atan(dl);
-        tab_kr[k] = 1.0 * fabs(ddl) / pow(1 + dl * dl, 1.5);
+        // (1 + y'^2)^1.5 as w * sqrt(w): within an ulp or two of the library power, like the
+        // device's own pow(), at a tenth of its instructions
+        const double w = 1 + dl * dl;
+        tab_kr[k] = 1.0 * fabs(ddl) / (w * __dsqrt_rn(w));
         const double dx = x - ex, dy = y - ey;
         const double d = __dsqrt_rn(dx * dx + dy * dy);
         if (d < best) { best = d; bi = k; }
