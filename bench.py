@@ -499,7 +499,7 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
                    "interval count"),
         stage_roof("front end (Frenet map, obstacle list)", "plan_frontend_kernel", flop_fe,
                    "(7 M + 40) flop per point to Frenet, M = the scene's reference-line samples; the kernel "
-                   "walks outwards from the nearest abscissa instead of visiting all M"),
+                   "compares only the samples of the blocks whose bounding box can hold the nearest one"),
     ]
     k = pmc.get("sl_plan_narrow_kernel", {})
     t_sl = stage_ms["SL path DP"] * 1e-3
