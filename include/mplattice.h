@@ -429,7 +429,7 @@ int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const
  * writes each stage's duration in milliseconds to stage_ms[MP_PLAN_N_STAGES]
  * (HOST memory); mp_plan_stage_name(i) names stage i.  Results in the arena as
  * from mp_plan_scenes.  Not for graph capture (creates and waits on events). */
-#define MP_PLAN_N_STAGES 13
+#define MP_PLAN_N_STAGES 8
 const char *mp_plan_stage_name(int32_t i);
 int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                          void *arena, int64_t arena_bytes, void *stream, float *stage_ms);

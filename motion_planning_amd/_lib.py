@@ -52,7 +52,7 @@ class PlanResult(C.Structure):       # mp_plan_result
 
 
 MP_PLAN_STATIC_BYTES = 32 << 20
-MP_PLAN_N_STAGES = 13
+MP_PLAN_N_STAGES = 8
 
 
 class PlanParams(C.Structure):       # mp_plan_params

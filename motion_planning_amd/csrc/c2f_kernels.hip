@@ -19,6 +19,7 @@
 #pragma clang fp contract(off)
 #include "mp_device.h"
 #include "c2f_device.h"
+#include "plan_glue.h"
 
 #define RL_SEG_CAP 128 // spline segments per reference line
 #define RL_ARC_CAP 128 // samples in one rectangle-rule piece
@@ -424,11 +425,8 @@ struct F2cDev {
 // One thread per point (cartesian_frenet_conversion.py:55-60 with get_rxy
 // :72-86): the first table abscissa whose arc length reaches s; past the table
 // the end of the line, whose ordinate/heading sit in the last slot +1.
-__global__ void f2c_kernel(F2cDev a)
+__device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int b)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_pts) return;
-    const int b = a.pt_scn ? a.pt_scn[p] : p / a.pts_per_scn;
     if (a.plan_status && p == b * a.pts_per_scn && a.plan_status[b] == MP_PLAN_OK) {
         // a scene whose profile or final path points were not produced must not read as
         // planned (PlannerInterface.run_step would raise IndexError from path_sampling,
@@ -458,6 +456,13 @@ __global__ void f2c_kernel(F2cDev a)
     a.y[p] = a.inv_y[o] + l * cos(th);
 }
 
+__global__ void f2c_kernel(F2cDev a)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_pts) return;
+    f2c_one(a, p, a.pt_scn ? a.pt_scn[p] : p / a.pts_per_scn);
+}
+
 struct CvDev {
     int32_t n_knots_max, q_max, mode;
     const double *knots_t, *knots_x;
@@ -476,17 +481,18 @@ struct CvDev {
 //   mode 1: samples get_arange(t0, t_last, dt)           (SpeedPlanner.plan, speed_planner.py:47)
 //   mode 2: samples given by the caller                  (path_sampling(curve, False, ss))
 // Dynamic LDS: tq[q_max] tsum[q_max] (double) seg[q_max] (int).
-__global__ void curve_eval_kernel(CvDev a)
+// (the body of curve_eval_kernel for curve b with npts knots; every thread of the
+// workgroup calls it, and a workgroup may call it again after a barrier)
+__device__ __forceinline__ void curve_eval_scene(const CvDev &a, const int b, const int npts, double *smem)
 {
-    extern __shared__ double smem[];
     __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
     __shared__ double Scum[RL_SEG_CAP]; // running end of the current segment in calc_point_arr's walk
     __shared__ double sc_d[2];          // fill step and end of the sample set
     __shared__ int sc_i[4];             // n samples, status, start segment / samples on the grid, ascending
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     double *tq = smem, *tsum = smem + a.q_max;
     int *seg = (int *)(smem + 2 * (size_t)a.q_max);
-    const int npts = a.n_knots[b], n = npts - 1;
+    const int n = npts - 1;
     const double *kt = a.knots_t + (size_t)b * a.n_knots_max;
     const double *kx = a.knots_x + (size_t)b * a.n_knots_max;
     if (n < 1 || n > RL_SEG_CAP || npts > a.n_knots_max) {
@@ -618,6 +624,116 @@ __global__ void curve_eval_kernel(CvDev a)
     }
 }
 
+__global__ void curve_eval_kernel(CvDev a)
+{
+    extern __shared__ double smem[];
+    curve_eval_scene(a, blockIdx.x, a.n_knots[blockIdx.x], smem);
+}
+
+// ---------------------------------------------------------------------------
+// Stages of the whole replan that depend on one another scene by scene, one workgroup
+// per scene (plan_glue.h).  A stage hands its arrays to the next one through global
+// memory, as the separate kernels did; the barrier between two stages makes a
+// workgroup's own writes visible to all of its threads.
+// ---------------------------------------------------------------------------
+__global__ void plan_path_kernel(PlanPathDev a)
+{
+    extern __shared__ double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int NS = a.n_s_max;
+    // outcome of the path search, read by every thread before anything is written
+    int st = a.status[b];
+    const int st_in = st;
+    const int n = a.n_layers[b];
+    if (st == MP_PLAN_OK && !a.track) {
+        const int sl = a.sl_status[b];
+        if (sl != MP_SL_FOUND) st = (sl == MP_SL_NOT_FOUND) ? MP_PLAN_NOT_FOUND : (sl < 0 ? sl : MP_PLAN_NOT_FOUND);
+    }
+    __syncthreads();
+    int32_t *pidx = a.path_idx + (size_t)b * NS;
+    if (a.track) {
+        // the centre node of every layer, or nothing for a scene that failed earlier
+        for (int s = tid; s < NS; s += nt) pidx[s] = (st_in == MP_PLAN_OK && s < n) ? a.mid_l : -1;
+        if (tid == 0) {
+            a.sl_status[b] = st_in == MP_PLAN_OK ? MP_SL_FOUND : MP_SL_SKIPPED;
+            a.layers_done[b] = st_in == MP_PLAN_OK ? n : 0;
+            a.best_cost[b] = __builtin_nan("");
+        }
+    }
+    const int npts = st == MP_PLAN_OK ? n + 1 : 0;
+    double *kt = a.knots_t + (size_t)b * (NS + 1), *kv = a.knots_v + (size_t)b * (NS + 1);
+    if (st == MP_PLAN_OK) {
+        const double *lay = a.s_layers + (size_t)b * NS;
+        for (int s = tid; s <= n; s += nt) {
+            kt[s] = s == 0 ? a.ego_sl[2 * b] : lay[s - 1];
+            kv[s] = s == 0 ? a.ego_sl[2 * b + 1] : a.l_row[a.track ? a.mid_l : pidx[s - 1]];
+        }
+    }
+    if (tid == 0) {
+        a.status[b] = st;
+        a.n_pk[b] = npts;
+    }
+    __syncthreads();
+    // the path every path_dt; a scene without knots reports MP_RL_E_INDEX and no samples
+    CvDev c{NS + 1, a.p_max, 0, a.knots_t, a.knots_v, a.n_pk, a.zeros, a.path_dt, nullptr, nullptr,
+            a.path_s, a.path_l, nullptr, a.n_path, a.path_status};
+    curve_eval_scene(c, b, npts, smem);
+    __syncthreads();
+    if (tid == 0) {
+        int n_s = 0;
+        if (st == MP_PLAN_OK) {
+            const int P = a.n_path[b];
+            if (a.path_status[b] != MP_RL_OK || P <= 0) st = MP_PLAN_E_ST_CAPACITY;
+            else {
+                const double s_end = a.path_s[(size_t)b * a.p_max + P - 1];
+                const double q = floor(s_end / a.st_ds);
+                if (!(q >= 0.0) || q + 1.0 > (double)a.st_n_s_max) st = MP_PLAN_E_ST_CAPACITY;
+                else n_s = (int)q + 1;
+            }
+        }
+        if (st != MP_PLAN_OK) a.n_path[b] = 0; // later stages skip the scene
+        a.st_n_s[b] = n_s;
+        a.status[b] = st;
+    }
+}
+
+__global__ void plan_tail_kernel(PlanTailDev a)
+{
+    extern __shared__ double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int n_t = a.n_t;
+    int st = a.status[b];
+    if (st == MP_PLAN_OK && a.reg_status[b] != MP_ST_OK) st = MP_PLAN_E_ST_CAPACITY;
+    const int len = st == MP_PLAN_OK ? a.st_path_len[b] : 0;
+    __syncthreads();
+    if (tid == 0) {
+        a.status[b] = st;
+        if (st != MP_PLAN_OK) a.st_path_len[b] = 0;
+    }
+    if (st == MP_PLAN_OK) {
+        for (int i = tid; i < n_t; i += nt) {
+            double t = 0.0;
+            for (int k = 0; k < i; ++k) t += a.st_dt; // t of knot i as the running sum reaches it
+            const int j = a.st_path_s_ind[(size_t)b * n_t + i];
+            a.sp_t[(size_t)b * n_t + i] = t;
+            a.sp_s[(size_t)b * n_t + i] = i < len ? (double)j * a.st_ds : 0.0;
+        }
+    }
+    __syncthreads();
+    CvDev prof{n_t, a.q_max, 1, a.sp_t, a.sp_s, a.st_path_len, a.robot_vel, a.curve_dt, nullptr, nullptr,
+               a.prof_t, a.ss, a.vv, a.n_prof, a.prof_status};
+    curve_eval_scene(prof, b, len, smem);
+    __syncthreads();
+    CvDev fin{a.n_pk_max, a.q_max, 2, a.knots_t, a.knots_v, a.n_pk, a.zeros, a.path_dt, a.ss, a.n_prof,
+              a.final_s, a.final_l, nullptr, a.n_final, a.final_status};
+    curve_eval_scene(fin, b, a.n_pk[b], smem);
+    __syncthreads();
+    F2cDev f{0, a.m_max, a.final_s, a.final_l, nullptr, a.q_max, a.n_final, a.inv_x, a.inv_s, a.inv_y,
+             a.inv_theta, nullptr, a.n_inv, a.final_x, a.final_y, a.status, a.prof_status, a.final_status,
+             a.n_prof};
+    for (int j = tid; j < a.q_max; j += nt) f2c_one(f, b * a.q_max + j, b);
+}
+
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
@@ -674,21 +790,21 @@ extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, con
     return c2f_launch_check("mp_f2c_batch");
 }
 
-// Frenet->Cartesian of pts_per_scn points per scene (scene-major), of which the
-// first n_valid[b] are converted and the rest set to 0.  Used by mp_plan_scenes,
-// whose last kernel this is: it also folds the outcome of the two spline
-// evaluations before it (prof_status, final_status, n_prof against n_valid) into
-// the scene's plan_status.
-int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
-                int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
-                const double *inv_theta, const int32_t *n_inv, double *x, double *y, int32_t *plan_status,
-                const int32_t *prof_status, const int32_t *final_status, const int32_t *n_prof, void *stream)
+// The two fused stages of the whole replan (plan_glue.h); sizes were checked by the chain.
+int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 {
-    const int n_pts = B * pts_per_scn;
-    F2cDev a{n_pts, m_max, s, l, nullptr, pts_per_scn, n_valid, inv_x, inv_s, inv_y, inv_theta, nullptr, n_inv,
-             x, y, plan_status, prof_status, final_status, n_prof};
-    hipLaunchKernelGGL(f2c_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return c2f_launch_check("mp_plan_scenes (frenet to cartesian)");
+    size_t lds = (size_t)a.p_max * (2 * sizeof(double) + sizeof(int));
+    lds = (lds + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(a.p_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_plan_scenes (path spline)");
+}
+
+int mp_plan_tail_stage(int32_t B, const PlanTailDev &a, void *stream)
+{
+    size_t lds = (size_t)a.q_max * (2 * sizeof(double) + sizeof(int));
+    lds = (lds + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(plan_tail_kernel, dim3(B), dim3(a.q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    return c2f_launch_check("mp_plan_scenes (speed profile and path points)");
 }
 
 extern "C" int mp_curve_eval(int32_t B, const double *knots_t, const double *knots_x, const int32_t *n_knots,

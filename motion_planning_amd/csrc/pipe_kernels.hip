@@ -9,25 +9,22 @@
 // widths and failure codes stay on the device as per-scene arrays.
 //
 // The heavy stages are the library's own entry points (mp_refline_tables,
-// mp_sl_plan, mp_curve_eval, mp_st_regions, mp_st_dp); this file adds the glue
-// the reference does in Python between them:
+// mp_sl_plan, mp_st_regions, mp_st_dp); this file adds the front end,
 //   plan_frontend_kernel  SLMap.create_frenet_map + add_obstacle (sl_map.py:33-112)
-//   plan_knots_kernel     knots of the path spline (path_planner.py:40-53)
-//   plan_stdims_kernel    STMap.__init__ grid width (st_map.py:13-22)
-//   plan_speed_kernel     knots of the speed spline (speed_planner.py:35-46)
+// and the short stages between them run as one kernel each, beside the spline
+// code (plan_glue.h): the path stage (knots of the path spline, its samples, ST
+// grid width) and the tail stage (knots of the speed spline, speed profile, path
+// points at the profile, those points in the robot frame).
 #pragma clang fp contract(off)
 #include "mp_device.h"
 #include "c2f_device.h"
+#include "plan_glue.h"
 
 #include <string.h>
 
 #include <mutex>
 
 extern void mp_set_error(const char *fmt, ...);
-int mp_f2c_rows(int32_t B, int32_t pts_per_scn, const int32_t *n_valid, const double *s, const double *l,
-                int32_t m_max, const double *inv_x, const double *inv_s, const double *inv_y,
-                const double *inv_theta, const int32_t *n_inv, double *x, double *y, int32_t *plan_status,
-                const int32_t *prof_status, const int32_t *final_status, const int32_t *n_prof, void *stream);
 int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
                           const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
                           const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
@@ -385,102 +382,6 @@ __global__ void plan_frontend_kernel(FrontDev a)
     }
 }
 
-struct GlueDev {
-    mp_plan_dims d;
-    PlanPtrs o;
-    double st_ds, st_dt;
-    int32_t mid_l, track;
-};
-
-// One thread per scene: outcome of the path search and the knots of the path
-// spline, [ego] + chosen nodes (path_planner.py:40-53; track_path_planner.py:25-35
-// takes the centre node of every layer).
-__global__ void plan_knots_kernel(GlueDev a)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.d.B) return;
-    const int NS = a.d.n_s_max;
-    int st = a.o.status[b];
-    const int n = a.o.n_layers[b];
-    int32_t *pidx = a.o.path_idx + (size_t)b * NS;
-    if (st == MP_PLAN_OK) {
-        if (a.track) {
-            for (int s = 0; s < NS; ++s) pidx[s] = s < n ? a.mid_l : -1;
-            a.o.sl_status[b] = MP_SL_FOUND;
-            a.o.layers_done[b] = n;
-            a.o.best_cost[b] = __builtin_nan("");
-        }
-        const int sl = a.o.sl_status[b];
-        if (sl != MP_SL_FOUND) st = (sl == MP_SL_NOT_FOUND) ? MP_PLAN_NOT_FOUND : (sl < 0 ? sl : MP_PLAN_NOT_FOUND);
-    } else if (a.track) {
-        for (int s = 0; s < NS; ++s) pidx[s] = -1;
-        a.o.sl_status[b] = MP_SL_SKIPPED;
-        a.o.layers_done[b] = 0;
-        a.o.best_cost[b] = __builtin_nan("");
-    }
-    a.o.status[b] = st;
-    double *kt = a.o.knots_t + (size_t)b * (NS + 1), *kv = a.o.knots_v + (size_t)b * (NS + 1);
-    if (st != MP_PLAN_OK) {
-        a.o.n_pk[b] = 0;
-        return;
-    }
-    kt[0] = a.o.ego_sl[2 * b];
-    kv[0] = a.o.ego_sl[2 * b + 1];
-    const double *lay = a.o.s_layers + (size_t)b * NS;
-    for (int s = 0; s < n; ++s) {
-        kt[s + 1] = lay[s];
-        kv[s + 1] = a.o.l_row[pidx[s]];
-    }
-    a.o.n_pk[b] = n + 1;
-}
-
-// One thread per scene: ST grid width n_s = floor(s_end / ds) + 1 with s_end the
-// arc length of the last path sample (planner_interface.py:145, st_map.py:17).
-__global__ void plan_stdims_kernel(GlueDev a)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.d.B) return;
-    int st = a.o.status[b];
-    int n_s = 0;
-    if (st == MP_PLAN_OK) {
-        const int P = a.o.n_path[b];
-        if (a.o.path_status[b] != MP_RL_OK || P <= 0) st = MP_PLAN_E_ST_CAPACITY;
-        else {
-            const double s_end = a.o.path_s[(size_t)b * a.d.p_max + P - 1];
-            const double q = floor(s_end / a.st_ds);
-            if (!(q >= 0.0) || q + 1.0 > (double)a.d.st_n_s_max) st = MP_PLAN_E_ST_CAPACITY;
-            else n_s = (int)q + 1;
-        }
-    }
-    if (st != MP_PLAN_OK) a.o.n_path[b] = 0; // later stages skip the scene
-    a.o.st_n_s[b] = n_s;
-    a.o.status[b] = st;
-}
-
-// One thread per scene: knots of the speed spline, t = 0, dt, 2dt, ... by
-// repeated addition and s = index * ds (speed_planner.py:35-46).
-__global__ void plan_speed_kernel(GlueDev a)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.d.B) return;
-    int st = a.o.status[b];
-    const int n_t = a.d.n_t;
-    if (st == MP_PLAN_OK && a.o.reg_status[b] != MP_ST_OK) st = MP_PLAN_E_ST_CAPACITY;
-    a.o.status[b] = st;
-    if (st != MP_PLAN_OK) {
-        a.o.st_path_len[b] = 0;
-        return;
-    }
-    const int len = a.o.st_path_len[b];
-    double t = 0.0;
-    for (int i = 0; i < n_t; ++i) {
-        const int j = a.o.st_path_s_ind[(size_t)b * n_t + i];
-        a.o.sp_t[(size_t)b * n_t + i] = t;
-        a.o.sp_s[(size_t)b * n_t + i] = i < len ? (double)j * a.st_ds : 0.0;
-        t += a.st_dt;
-    }
-}
-
 // ---------------------------------------------------------------------------
 static int pipe_launch_check(const char *what)
 {
@@ -599,17 +500,10 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
     }
     PLAN_STAGE_DONE();
 
-    GlueDev g;
-    g.d = d;
-    g.o = o;
-    g.st_ds = p.st_ds;
-    g.st_dt = p.st_dt;
-    g.mid_l = mid_l;
-    g.track = p.path_planner == 1;
-    const dim3 per_scene((B + 127) / 128), blk(128);
+    const bool track = p.path_planner == 1;
 
     // 3. path search over the lattice
-    if (!g.track) {
+    if (!track) {
         mp_sl_batch sb;
         sb.B = B;
         sb.n_s = d.n_s_max;
@@ -633,22 +527,24 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         if (rc) return rc;
     }
     PLAN_STAGE_DONE();
-    // 4. knots of the path spline, 5. the path every path_dt
-    hipLaunchKernelGGL(plan_knots_kernel, per_scene, blk, 0, st, g);
-    rc = pipe_launch_check("mp_plan_scenes (path knots)");
-    if (rc) return rc;
-    PLAN_STAGE_DONE();
-    const double *zero_vec = o.zeros; // end slope 0.0 (path_planner.py:53)
-    rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 0, nullptr, nullptr,
-                       d.p_max, o.path_s, o.path_l, nullptr, o.n_path, o.path_status, stream);
-    if (rc) return rc;
+    // 4. knots of the path spline, the path every path_dt, ST grid width (one kernel)
+    {
+        PlanPathDev a;
+        a.n_s_max = d.n_s_max; a.p_max = d.p_max; a.st_n_s_max = d.st_n_s_max; a.track = track; a.mid_l = mid_l;
+        a.path_dt = p.path_dt; a.st_ds = p.st_ds;
+        a.status = o.status; a.sl_status = o.sl_status; a.layers_done = o.layers_done; a.path_idx = o.path_idx;
+        a.n_layers = o.n_layers; a.best_cost = o.best_cost;
+        a.ego_sl = o.ego_sl; a.s_layers = o.s_layers; a.l_row = o.l_row;
+        a.zeros = o.zeros; // end slope 0.0 (path_planner.py:53)
+        a.knots_t = o.knots_t; a.knots_v = o.knots_v; a.n_pk = o.n_pk;
+        a.path_s = o.path_s; a.path_l = o.path_l; a.n_path = o.n_path; a.path_status = o.path_status;
+        a.st_n_s = o.st_n_s;
+        rc = mp_plan_path_stage(B, a, stream);
+        if (rc) return rc;
+    }
     PLAN_STAGE_DONE();
 
-    // 6. ST grid width, 7. blocked intervals, 8. speed search
-    hipLaunchKernelGGL(plan_stdims_kernel, per_scene, blk, 0, st, g);
-    rc = pipe_launch_check("mp_plan_scenes (ST grid)");
-    if (rc) return rc;
-    PLAN_STAGE_DONE();
+    // 5. blocked intervals, 6. speed search
     rc = mp_st_regions_strided(B, d.n_t, o.path_s, o.path_l, o.n_path, d.p_max, o.st_s, o.st_l, in.st_rad, in.n_st,
                                d.n_st_max, o.dy_s, o.dy_l, in.dy_rad, in.n_dy, d.n_dy_max, d.n_frames, d.r_max,
                                o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream);
@@ -660,24 +556,25 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
     if (rc) return rc;
     PLAN_STAGE_DONE();
 
-    // 9. speed profile every dt/5, 10. path points at its arc lengths, 11. back to the robot frame
-    hipLaunchKernelGGL(plan_speed_kernel, per_scene, blk, 0, st, g);
-    rc = pipe_launch_check("mp_plan_scenes (speed knots)");
-    if (rc) return rc;
-    PLAN_STAGE_DONE();
-    const double curve_dt = p.st_dt * 1.0 / 5; // speed_planner.py:22
-    rc = mp_curve_eval(B, o.sp_t, o.sp_s, o.st_path_len, d.n_t, o.robot_vel, curve_dt, 1, nullptr, nullptr, d.q_max,
-                       o.prof_t, o.ss, o.vv, o.n_prof, o.prof_status, stream);
-    if (rc) return rc;
-    PLAN_STAGE_DONE();
-    rc = mp_curve_eval(B, o.knots_t, o.knots_v, o.n_pk, d.n_s_max + 1, zero_vec, p.path_dt, 2, o.ss, o.n_prof,
-                       d.q_max, o.final_s, o.final_l, nullptr, o.n_final, o.final_status, stream);
-    if (rc) return rc;
-    PLAN_STAGE_DONE();
-    rc = mp_f2c_rows(B, d.q_max, o.n_final, o.final_s, o.final_l, d.m_max, o.inv_x, o.inv_s, o.inv_y,
-                     o.inv_theta, o.n_inv, o.final_x, o.final_y, o.status, o.prof_status, o.final_status,
-                     o.n_prof, stream);
-    if (rc) return rc;
+    // 7. knots of the speed spline, speed profile every dt/5, path points at its arc lengths,
+    //    those points back in the robot frame, final status (one kernel)
+    {
+        PlanTailDev a;
+        a.n_t = d.n_t; a.n_pk_max = d.n_s_max + 1; a.q_max = d.q_max; a.m_max = d.m_max;
+        a.st_ds = p.st_ds; a.st_dt = p.st_dt;
+        a.curve_dt = p.st_dt * 1.0 / 5; // speed_planner.py:22
+        a.path_dt = p.path_dt;
+        a.status = o.status; a.reg_status = o.reg_status;
+        a.st_path_len = o.st_path_len; a.st_path_s_ind = o.st_path_s_ind;
+        a.sp_t = o.sp_t; a.sp_s = o.sp_s; a.robot_vel = o.robot_vel; a.zeros = o.zeros;
+        a.knots_t = o.knots_t; a.knots_v = o.knots_v; a.n_pk = o.n_pk;
+        a.prof_t = o.prof_t; a.ss = o.ss; a.vv = o.vv; a.n_prof = o.n_prof; a.prof_status = o.prof_status;
+        a.final_s = o.final_s; a.final_l = o.final_l; a.n_final = o.n_final; a.final_status = o.final_status;
+        a.inv_x = o.inv_x; a.inv_s = o.inv_s; a.inv_y = o.inv_y; a.inv_theta = o.inv_theta; a.n_inv = o.n_inv;
+        a.final_x = o.final_x; a.final_y = o.final_y;
+        rc = mp_plan_tail_stage(B, a, stream);
+        if (rc) return rc;
+    }
     PLAN_STAGE_DONE();
 #undef PLAN_STAGE_DONE
     if (stage_ev && stage_no != MP_PLAN_N_STAGES) {
@@ -689,8 +586,8 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
 
 static const char *const g_stage_names[MP_PLAN_N_STAGES] = {
     "clear result rows (memset)", "reference-line tables", "front end (Frenet map, obstacle list)",
-    "SL path DP", "path spline knots", "path sampling", "ST grid width", "ST blocked intervals", "ST speed DP",
-    "speed spline knots", "speed profile", "path points at the profile", "Frenet to Cartesian"};
+    "SL path DP", "path spline (knots, samples, ST grid width)", "ST blocked intervals", "ST speed DP",
+    "speed profile, path points, Frenet to Cartesian"};
 
 extern "C" const char *mp_plan_stage_name(int32_t i)
 {
