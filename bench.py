@@ -17,11 +17,17 @@ take disjoint contiguous blocks of scenarios and nothing else is exchanged.
 With N > 1 and no launcher in the environment the script starts its own N ranks
 (torch.distributed.run) before it touches the GPU.
 
-Prints ONE JSON line (rank 0): plans/sec of the timed steps (median of --reps
-timed blocks of K steps each), the per-kernel rooflines, the same workload with
-the host->device copies of its inputs inside the step, the CPU oracle timed on a
-sample of the same batch (and its results compared with the GPU's), and a short
-run of the whole-replan workload (--workload pipeline makes that the headline).
+The steps are timed twice (median of --reps timed blocks of K steps each).  First on
+one stream with HIP events around every launch: the kernel times and rooflines.
+Then with the batch cut into --streams parts (default 2), part k on stream k: SL
+plan -> ST DP per part, no part waiting for another, so that the tail of one part's
+kernel runs beside the other part's; that is the headline (`value`), the one-stream
+rate is printed beside it (`value_one_stream`; --streams 1 makes it the headline).
+
+Prints ONE JSON line (rank 0): plans/sec, the per-kernel rooflines, the same
+workload with the host->device copies of its inputs inside the step, the CPU oracle
+timed on a sample of the same batch (and its results compared with the GPU's), and
+a short run of the whole-replan workload (--workload pipeline makes that the headline).
 """
 import argparse
 import json
@@ -259,6 +265,33 @@ class ResultGather:
         if self.pending[i] is not None:
             self.pending[i].wait()
         self.mdist.pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=self.packed[i][:self.B])
+        src = self.packed[i] if self.backend == "nccl" else self.packed[i].cpu()
+        self.pending[i] = self.mdist.gather_results_same_size(src, self.gathered[i], async_op=True)
+        self.k += 1
+
+    def submit_parts(self, parts):
+        """The same exchange for a batch whose parts were planned on streams of their own:
+        parts = [(lo, hi, stream, (path_idx, status, layers_done, best_cost, st_path, st_len))].
+        Each part packs its rows on its own stream; the collective waits for every part,
+        no part waits for another."""
+        if not self.active:
+            return
+        import torch
+        main = torch.cuda.current_stream()
+        i = self.k & 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()             # the collective that read packed[i] two steps ago
+            self.pending[i] = None
+            freed = torch.cuda.Event()
+            freed.record(main)
+            for _lo, _hi, stream, _o in parts:
+                stream.wait_event(freed)
+        for lo, hi, stream, o in parts:
+            with torch.cuda.stream(stream):
+                self.mdist.pack_results(*o, out=self.packed[i][lo:hi])
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            main.wait_event(ev)
         src = self.packed[i] if self.backend == "nccl" else self.packed[i].cpu()
         self.pending[i] = self.mdist.gather_results_same_size(src, self.gathered[i], async_op=True)
         self.k += 1
@@ -661,6 +694,44 @@ class H2DLoop:
         return s
 
 
+class SplitLoop:
+    """The step with the batch cut into parts that never wait for one another: part k runs
+    SL plan -> ST DP (-> its result records) on stream k.  Scenarios are independent, so
+    this is the same work on the same kernels; what changes is that the tail of one part's
+    kernel (the last workgroups, which leave most of the GPU idle) runs beside the other
+    part's kernels, also across steps.  Only the result exchange looks at all parts."""
+
+    def __init__(self, sc, prm, gather, n_parts, maps):
+        import torch
+        from motion_planning_amd import batch as mb, dist as mdist
+        self.torch, self.mb, self.prm, self.gather, self.maps = torch, mb, prm, gather, maps
+        B = sc["s_layers"].shape[0]
+        self.parts = []
+        for k in range(n_parts):
+            lo, hi = mdist.shard_range(B, k, n_parts)
+            sb = mb.SLBatch(sc["s_layers"][lo:hi], sc["l_row"][lo:hi], sc["ego"][lo:hi], sc["ob_s"][lo:hi],
+                            sc["ob_l"][lo:hi], sc["n_ob"][lo:hi], sc["ob_dist"][lo:hi])
+            st_in = (mb.to_dev(sc["st_n_s"][lo:hi], torch.int32), mb.to_dev(sc["down"][lo:hi]),
+                     mb.to_dev(sc["up"][lo:hi]), mb.to_dev(sc["n_reg"][lo:hi], torch.int32),
+                     mb.to_dev(sc["cur_vel"][lo:hi]))
+            self.parts.append(dict(lo=lo, hi=hi, sb=sb, out=mb.SLPlanOut(hi - lo, N_S, N_L, want_maps=maps),
+                                   st_in=st_in, st=None, stream=torch.cuda.Stream()))
+        torch.cuda.synchronize()   # inputs were staged on the current stream
+
+    def step(self, _i=None):
+        torch, mb = self.torch, self.mb
+        for p in self.parts:
+            with torch.cuda.stream(p["stream"]):
+                mb.sl_plan(p["sb"], self.prm, p["out"])
+                p["st"] = mb.st_dp(*p["st_in"], SPEED_LIM, want_tables=self.maps, n_s_max=ST_N_S, out=p["st"])
+        self.gather.submit_parts([(p["lo"], p["hi"], p["stream"],
+                                   (p["out"].path_idx, p["out"].status, p["out"].layers_done, p["out"].best_cost,
+                                    p["st"]["path_s_ind"], p["st"]["path_len"])) for p in self.parts])
+
+    def cat(self, get):
+        return self.torch.cat([get(p) for p in self.parts])
+
+
 def bench_lattice(args, job):
     import torch
     from motion_planning_amd import batch as mb, dist as mdist
@@ -712,7 +783,9 @@ def bench_lattice(args, job):
     assert bad == 0, "kernel reported %d scenarios with an error status" % bad
     assert int(st["path_len"].min()) >= 2
 
-    if job.dist_on:
+    def check_exchange():
+        if not job.dist_on:
+            return
         # every rank holds every scenario's record, in scenario order
         u = mdist.unpack_results(gather.rows_of(rank, B).to("cuda"), N_S, ST_N_T)
         assert torch.equal(u["path_idx"], out.path_idx) and torch.equal(u["st_path"], st["path_s_ind"])
@@ -723,6 +796,23 @@ def bench_lattice(args, job):
                       else (r * B, (r + 1) * B))
             n_all += int((mdist.unpack_results(gather.rows_of(r, hi - lo), N_S, ST_N_T)["st_len"] >= 2).sum())
         assert n_all == job.total, "gathered %d complete records of %d" % (n_all, job.total)
+
+    check_exchange()
+
+    # the same steps with the batch cut into parts on streams of their own (see SplitLoop)
+    split_secs = None
+    if args.streams > 1 and B >= 64 * args.streams:
+        split = SplitLoop(sc, prm, gather, args.streams, bool(args.maps))
+        for _ in range(max(2, args.warmup)):
+            split.step()
+        gather.drain()
+        split_secs = timed_blocks(job, split.step, gather.drain, steps, reps)
+        torch.cuda.synchronize()
+        assert torch.equal(split.cat(lambda p: p["out"].path_idx), out.path_idx)
+        assert torch.equal(split.cat(lambda p: p["out"].status), out.status)
+        assert torch.equal(split.cat(lambda p: p["st"]["path_s_ind"]), st["path_s_ind"])
+        assert torch.equal(split.cat(lambda p: p["st"]["path_len"]), st["path_len"])
+        check_exchange()
 
     # the step again with the host->device copies of its inputs inside (never `value`)
     h2d = None
@@ -747,6 +837,10 @@ def bench_lattice(args, job):
 
     if rank != 0:
         return None
+    one_sec = float(np.median(secs))
+    one_secs = secs
+    if split_secs:      # the headline is the schedule a caller would use; the kernels are timed alone
+        secs = split_secs
     sec = float(np.median(secs))
     plans_per_s = job.total * steps / sec
     k_samples = 4  # samples per edge at a 1.5 m layer gap and 0.5 m spacing
@@ -822,6 +916,15 @@ def bench_lattice(args, job):
                    "parallelism": "scenario-sharded x%d" % world},
         "edges_evaluated_per_sec": world * edges_eval / (sl_ms * 1e-3) if edges_eval else None,
         "lattice_edges_nominal_per_sec": world * edges_nominal / (sl_ms * 1e-3),
+        "schedule": ("the batch in %d parts on %d streams, each part SL plan -> ST DP on its own stream; parts "
+                     "never wait for one another (scenarios are independent), so one part's kernels fill the "
+                     "tail of the other's, also across steps" % (args.streams, args.streams)) if split_secs
+                    else "one stream: SL plan -> ST DP over the whole batch",
+        "value_one_stream": job.total * steps / one_sec,
+        "ms_per_step_one_stream": 1e3 * one_sec / steps,
+        "ms_per_step_one_stream_min": 1e3 * min(one_secs) / steps,
+        "kernel_times": "sl_kernel_ms / st_kernel_ms and every roofline: HIP events around each launch in the "
+                        "one-stream timed blocks of this run (whole batch per launch, a kernel alone on the GPU)",
         "sl_kernel_ms": sl_ms, "st_kernel_ms": st_ms, "found_fraction": found_frac,
         "roofline": dominant,
         "roofline_other": roof_st if dominant is roof_sl else roof_sl,
@@ -833,9 +936,9 @@ def bench_lattice(args, job):
         res["value_with_h2d"] = job.total * steps / hsec
         res["h2d"] = {"ms_per_step": 1e3 * hsec / steps, "bytes_per_step_rank0": nbytes,
                       "copy_only_ms_at_63GBps": nbytes / 63e9 * 1e3,
-                      "note": "same step, inputs copied from one pinned staging buffer inside it (one copy per step "
-                              "on a copy stream), double-buffered so the copy of step i+1 runs beside the kernels of "
-                              "step i"}
+                      "note": "the one-stream step (compare value_one_stream) with its inputs copied from one pinned "
+                              "staging buffer inside it (one copy per step on a copy stream), double-buffered so the "
+                              "copy of step i+1 runs beside the kernels of step i"}
     if args.materialised > 0 and world == 1:
         res["roofline_materialised"] = materialised_roofline(sc, min(args.materialised, B), prm)
     if args.cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
@@ -875,6 +978,9 @@ def main():
     ap.add_argument("--materialised", type=int, default=1024,
                     help="scenarios run through the two-kernel SL path for its HBM roofline (0 = skip)")
     ap.add_argument("--maps", type=int, default=0, help="1 = also write cost_map/index_map/ST tables to HBM")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="parts the batch is cut into for the headline step, each on a stream of its own "
+                         "(1 = the whole batch on one stream)")
     ap.add_argument("--h2d-reps", type=int, default=5, help="timed blocks of the host-to-device variant (0 = skip)")
     ap.add_argument("--pipeline-steps", type=int, default=10,
                     help="steps per timed block of the whole-replan leg attached to the lattice line (0 = skip)")

@@ -16,6 +16,28 @@
 
 #include "mp_device.h"
 
+#ifdef ST_COUNT
+// Development aid, built only with -DST_COUNT (tools/count_st.py): what the walks of the
+// split relaxation do.  0 wave steps, 1 lane steps (edges priced), 2 wave steps that took
+// the quiet obstacle sum, 4 lanes stopped by the bound, 5 wave passes, 8 first wave steps,
+// 9 / 10 later lane steps that did / did not improve the lane's best.
+__device__ unsigned long long st_cnt[16];
+#define ST_CNT_WAVE(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&st_cnt[i], 1ull); } while (0)
+#define ST_CNT_LANE(i) atomicAdd(&st_cnt[i], 1ull)
+extern "C" int mp_debug_st_counters(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(st_cnt), sizeof(st_cnt)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(st_cnt), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define ST_CNT_WAVE(i) do {} while (0)
+#define ST_CNT_LANE(i) do {} while (0)
+#endif
+
 struct StDev {
     int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
     int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
@@ -327,11 +349,13 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
             auto step = [&](int e, auto first) -> bool {
                 constexpr bool FIRST = decltype(first)::value;
                 const double2 fsv = *(const double2 *)((const char *)sh.fs + e);
+                ST_CNT_WAVE(0); ST_CNT_LANE(1);
+                if (FIRST) ST_CNT_WAVE(8);
                 // the lanes of a wave hold neighbouring cells at nearly the same distance, so
                 // "no lane needs the front formula" is common (slow edges, obstacles far ahead)
                 // and decided for the whole wave
                 double obv;
-                if (RT > 0 && __ballot(e >= e_quiet) == 0ull) obv = ob_quiet;
+                if (RT > 0 && __ballot(e >= e_quiet) == 0ull) { obv = ob_quiet; ST_CNT_WAVE(2); }
                 else {
                     const double fsum = __dadd_rn(fsv.x, s);
                     obv = 0.0;
@@ -345,7 +369,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 }
                 const double base = __dadd_rn(obv, fsv.y);
                 if constexpr (!FIRST)
-                    if (e >= e_brk && __dadd_rn(base, m_prev) > best) return true;
+                    if (e >= e_brk && __dadd_rn(base, m_prev) > best) { ST_CNT_LANE(4); return true; }
                 // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
                 const double2 chv = *(const double2 *)(ch_j - e);
                 const int h = __double2loint(chv.y);
@@ -353,6 +377,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 const double jv = *(const double *)(jerk_j + (h >> 16));
                 const double tot = __dadd_rn(__dadd_rn(base, av), jv);
                 const double c = __dadd_rn(tot, chv.x);
+                if (!FIRST) { if (c <= best) ST_CNT_LANE(9); else ST_CNT_LANE(10); }
                 if (FIRST || c <= best) { best = c; be = e; }
                 return false;
             };
@@ -364,6 +389,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
             }
             if (be >= 0) bp = j - (be >> 4);
         }
+        ST_CNT_WAVE(5);
         group_argmin<ST_SPLIT>(best, bp);
         if (live && r == 0) {
             sh.cost_cur(j) = best;
