@@ -488,6 +488,42 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     if job.dist_on:
         u = mdist.unpack_results(gather.rows_of(rank, B).to("cuda"), dims.n_s_max, dims.n_t)
         assert torch.equal(u["path_idx"], a["path_idx"]) and torch.equal(u["st_path"], a["st_path_s_ind"])
+    # the same steps with the scenes cut into parts, each part's whole chain on a stream of
+    # its own with an arena of its own (see SplitLoop): eight launches per part, and the
+    # tail of every one of them runs beside the other part's kernels
+    split_secs = None
+    n_parts = args.streams
+    if n_parts > 1 and B >= 64 * n_parts:
+        parts = []
+        for k in range(n_parts):
+            lo, hi = mdist.shard_range(B, k, n_parts)
+            pdims = pl.plan_dims(hi - lo, sc["knots_x"].shape[1], sc["st_pos"].shape[1], sc["dy_pos"].shape[1],
+                                 n_l=5, m_max=200, params=params)
+            parts.append(dict(lo=lo, hi=hi, dev={kk: v[lo:hi].contiguous() for kk, v in dev.items()}, dims=pdims,
+                              arena=pl.PlanArena(pdims), stream=torch.cuda.Stream()))
+        torch.cuda.synchronize()
+
+        def split_step(_i=None):
+            for p in parts:
+                with torch.cuda.stream(p["stream"]):
+                    pl.plan_scenes(p["dev"], p["dims"], params, p["arena"])
+            gather.submit_parts([(p["lo"], p["hi"], p["stream"],
+                                  tuple(p["arena"].arrays[kk] for kk in ("path_idx", "sl_status", "layers_done",
+                                                                         "best_cost", "st_path_s_ind", "st_path_len")))
+                                 for p in parts])
+
+        for _ in range(max(2, warmup)):
+            split_step()
+        gather.drain()
+        split_secs = timed_blocks(job, split_step, gather.drain, steps, reps)
+        torch.cuda.synchronize()
+        for kk in ("status", "n_final", "path_idx", "st_path_s_ind", "final_x", "final_y", "vv"):
+            got = torch.cat([p["arena"].arrays[kk] for p in parts])
+            assert torch.equal(got, a[kk]) or (got.is_floating_point() and
+                                               torch.equal(got.nan_to_num(), a[kk].nan_to_num())), kk
+        if job.dist_on:
+            u = mdist.unpack_results(gather.rows_of(rank, B).to("cuda"), dims.n_s_max, dims.n_t)
+            assert torch.equal(u["path_idx"], a["path_idx"]) and torch.equal(u["st_path"], a["st_path_s_ind"])
     status = a["status"].cpu().numpy()
     assert set(np.unique(status)) <= {1, 0, -4}, "unexpected scene status %s" % np.unique(status)
     n_final = a["n_final"].cpu().numpy()
@@ -500,6 +536,9 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     stage = [(n, t / 3.0) for n, t in stage]
     if rank != 0:
         return None
+    one_sec = float(np.median(secs))
+    if split_secs:
+        secs = split_secs
     sec = float(np.median(secs))
     ms = 1e3 * sec / steps
     stage_ms = dict(stage)
@@ -559,6 +598,11 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
                                "layers every 8 m), default ST grid; one mp_plan_scenes call per step" % B,
                    "scenarios_per_gpu": B, "n_l": 5, "n_st": 192, "n_dy": 64,
                    "parallelism": "scenario-sharded x%d" % world},
+        "schedule": ("the scenes in %d parts on %d streams, one mp_plan_scenes call per part and step, parts never "
+                     "wait for one another" % (n_parts, n_parts)) if split_secs
+                    else "one stream: one mp_plan_scenes call over all scenes per step",
+        "value_one_stream": world * B * steps / one_sec, "ms_per_step_one_stream": 1e3 * one_sec / steps,
+        "stage_times": "stage_ms and the rooflines: HIP events between the stages of one-stream calls over all scenes",
         "c2f_points_per_sec": world * n_pts * steps / sec,
         "status_fractions": {"planned": float((status == 1).mean()), "no_path": float((status == 0).mean()),
                              "map_longer_than_100m": float((status == -4).mean())},
