@@ -13,7 +13,7 @@ pipeline = "--pipeline" in sys.argv
 src = args[0]
 scenarios = int(args[1]) if len(args) > 1 else 4096
 KERNELS = (("st_dp_kernel", "plan_frontend_kernel", "sl_plan_narrow_kernel", "refline_tables_kernel",
-            "st_regions_once_kernel", "curve_eval_kernel") if pipeline else
+            "st_regions_once_kernel", "plan_path_kernel", "plan_tail_kernel") if pipeline else
            ("sl_plan_kernel", "st_dp_kernel", "sl_dp_kernel", "sl_edge_cost_kernel"))
 k = {}
 for line in open(src):
