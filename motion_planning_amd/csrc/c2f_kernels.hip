@@ -425,7 +425,10 @@ struct F2cDev {
 // One thread per point (cartesian_frenet_conversion.py:55-60 with get_rxy
 // :72-86): the first table abscissa whose arc length reaches s; past the table
 // the end of the line, whose ordinate/heading sit in the last slot +1.
-__device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int b)
+// arc: the scene's arc-length table (null: read it from a.inv_s); ascending: the table was
+// checked to never decrease, so the first entry that reaches s is found by bisection.
+__device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int b, const double *arc_tab = nullptr,
+                                        const bool ascending = false)
 {
     if (a.plan_status && p == b * a.pts_per_scn && a.plan_status[b] == MP_PLAN_OK) {
         // a scene whose profile or final path points were not produced must not read as
@@ -442,10 +445,19 @@ __device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int 
     }
     const int n = a.n_inv[b];
     const double s = a.s[p], l = a.l[p];
-    const double *arc = a.inv_s + (size_t)b * a.m_max;
+    const double *arc = arc_tab ? arc_tab : a.inv_s + (size_t)b * a.m_max;
     int k = n - 1; // the table ends on rx_max (get_arange appends it)
-    for (int i = 0; i < n; ++i)
-        if (s <= arc[i]) { k = i; break; }
+    if (ascending) {
+        int lo = 0, hi = n; // first index with s <= arc[index], n if none (also for a NaN s)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s <= arc[mid]) hi = mid; else lo = mid + 1;
+        }
+        if (lo < n) k = lo;
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (s <= arc[i]) { k = i; break; }
+    }
     if (n <= 0) {
         a.x[p] = a.y[p] = __builtin_nan("");
         return;
@@ -731,7 +743,19 @@ __global__ void plan_tail_kernel(PlanTailDev a)
     F2cDev f{0, a.m_max, a.final_s, a.final_l, nullptr, a.q_max, a.n_final, a.inv_x, a.inv_s, a.inv_y,
              a.inv_theta, nullptr, a.n_inv, a.final_x, a.final_y, a.status, a.prof_status, a.final_status,
              a.n_prof};
-    for (int j = tid; j < a.q_max; j += nt) f2c_one(f, b * a.q_max + j, b);
+    // the scene's arc-length table once into LDS (the spline evaluations are done with it);
+    // a table that never decreases -- every table of a sound reference line -- is bisected
+    const int n_inv = a.n_inv[b];
+    const bool staged = n_inv > 0 && n_inv <= a.m_max;
+    int descends = 0;
+    if (staged) {
+        for (int i = tid; i < n_inv; i += nt) smem[i] = a.inv_s[(size_t)b * a.m_max + i];
+        __syncthreads();
+        for (int i = tid; i + 1 < n_inv; i += nt) descends |= !(smem[i] <= smem[i + 1]);
+    }
+    descends = __syncthreads_or(descends);
+    for (int j = tid; j < a.q_max; j += nt)
+        f2c_one(f, b * a.q_max + j, b, staged ? smem : nullptr, staged && !descends);
 }
 
 // ---------------------------------------------------------------------------
@@ -802,6 +826,7 @@ int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 int mp_plan_tail_stage(int32_t B, const PlanTailDev &a, void *stream)
 {
     size_t lds = (size_t)a.q_max * (2 * sizeof(double) + sizeof(int));
+    if (lds < (size_t)a.m_max * sizeof(double)) lds = (size_t)a.m_max * sizeof(double); // the arc-length table
     lds = (lds + 15) & ~(size_t)15;
     hipLaunchKernelGGL(plan_tail_kernel, dim3(B), dim3(a.q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (speed profile and path points)");
