@@ -25,12 +25,19 @@
 #include <mutex>
 
 extern void mp_set_error(const char *fmt, ...);
+int mp_sl_plan_keyed(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map, int32_t *index_map,
+                     int32_t *path_idx, int32_t *status, int32_t *layers_done, double *best_cost,
+                     int32_t *order_ws, void *stream);
+int mp_st_dp_keyed(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+                   const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+                   double speed_lim, double ds, double dt, double *cost, int32_t *pre, int32_t *path_s_ind,
+                   int32_t *path_len, int32_t *order_ws, void *stream);
 int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
                           const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
                           const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
                           const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
                           int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
-                          int32_t *status, void *stream);
+                          int32_t *status, void *stream, const int32_t *key_n_s, int32_t *key_out);
 
 // ---------------------------------------------------------------------------
 // Arena layout: X(name, C type, MP_F64 / MP_I32, dim0, dim1, dim2, dim3)
@@ -231,7 +238,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
 {
     extern __shared__ double smem[];
     __shared__ int wave_cnt[16];
-    __shared__ int base_sh;
+    __shared__ int base_sh, nlay_sh;
     __shared__ double rmax_sh[16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
@@ -255,6 +262,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
             a.o.status[b] = line_ok ? MP_PLAN_E_MAP_TOO_BIG : MP_PLAN_E_BAD_LINE;
             a.o.n_layers[b] = 0;
             a.o.n_ob[b] = 0;
+            a.o.order_ws[b] = 0;
             a.o.ob_dist[b] = 0.0;
             a.o.ego_sl[2 * b] = a.o.ego_sl[2 * b + 1] = a.o.robot_vel[b] = __builtin_nan("");
         }
@@ -313,6 +321,7 @@ __global__ void plan_frontend_kernel(FrontDev a)
             }
         }
         a.o.n_layers[b] = full ? 0 : n;
+        nlay_sh = full ? 0 : n;
         a.o.status[b] = full ? MP_PLAN_E_CAPACITY : MP_PLAN_OK;
     }
 
@@ -379,6 +388,9 @@ __global__ void plan_frontend_kernel(FrontDev a)
         for (int w = 1; w < nw; ++w) r = rmax_sh[w] > r ? rmax_sh[w] : r;
         a.o.n_ob[b] = base_sh;
         a.o.ob_dist[b] = r; // max radius of the kept entries (sl_map.py:94,106), 0 if none
+        // the scene's weight for the ordered path search: obstacle entries x layers
+        // (what sl_weight_narrow_kernel would compute from these two counts)
+        a.o.order_ws[b] = mp_weight_bin((double)(base_sh + 1) * (double)nlay_sh);
     }
 }
 
@@ -522,8 +534,8 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         mp_sl_params sp = p.sl;
         sp.mid_l = mid_l;
         // (scenes differ in obstacles and layers by an order of magnitude: heaviest first)
-        rc = mp_sl_plan_ordered(&sb, &sp, o.cost_map, o.index_map, o.path_idx, o.sl_status, o.layers_done,
-                                o.best_cost, o.order_ws, stream);
+        rc = mp_sl_plan_keyed(&sb, &sp, o.cost_map, o.index_map, o.path_idx, o.sl_status, o.layers_done,
+                              o.best_cost, o.order_ws, stream);
         if (rc) return rc;
     }
     PLAN_STAGE_DONE();
@@ -547,12 +559,12 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
     // 5. blocked intervals, 6. speed search
     rc = mp_st_regions_strided(B, d.n_t, o.path_s, o.path_l, o.n_path, d.p_max, o.st_s, o.st_l, in.st_rad, in.n_st,
                                d.n_st_max, o.dy_s, o.dy_l, in.dy_rad, in.n_dy, d.n_dy_max, d.n_frames, d.r_max,
-                               o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream);
+                               o.st_down, o.st_up, o.st_n_reg, o.reg_status, stream, o.st_n_s, o.order_ws);
     if (rc) return rc;
     PLAN_STAGE_DONE();
-    rc = mp_st_dp_ordered(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
-                          p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len,
-                          o.order_ws, stream);
+    rc = mp_st_dp_keyed(B, d.n_t, d.st_n_s_max, o.st_n_s, o.st_down, o.st_up, o.st_n_reg, d.r_max, o.robot_vel,
+                        p.speed_lim, p.st_ds, p.st_dt, o.st_cost, o.st_pre, o.st_path_s_ind, o.st_path_len,
+                        o.order_ws, stream);
     if (rc) return rc;
     PLAN_STAGE_DONE();
 

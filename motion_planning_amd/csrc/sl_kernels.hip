@@ -1792,7 +1792,8 @@ static int launch_check(const char *what)
 
 static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
-                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream);
+                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream,
+                          bool keys_ready = false);
 
 extern "C" int mp_sl_plan(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
@@ -1810,6 +1811,17 @@ extern "C" int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *
                           order_ws, stream);
 }
 
+// mp_sl_plan_ordered for the whole replan, whose front end has already left every scene's weight
+// bin (sl_weight_narrow_kernel's value) in order_ws[0..B); lattices of more than 16 lanes take
+// their own weights as usual.
+int mp_sl_plan_keyed(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map, int32_t *index_map,
+                     int32_t *path_idx, int32_t *status, int32_t *layers_done, double *best_cost,
+                     int32_t *order_ws, void *stream)
+{
+    return sl_plan_launch(batch, params, cost_map, index_map, path_idx, status, layers_done, best_cost, nullptr,
+                          order_ws, stream, true);
+}
+
 extern "C" int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
                                   int32_t *status, int32_t *layers_done, double *best_cost,
                                   uint64_t *n_evaluated, void *stream)
@@ -1825,7 +1837,8 @@ extern "C" int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *
 
 static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, double *cost_map,
                           int32_t *index_map, int32_t *path_idx, int32_t *status, int32_t *layers_done,
-                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream)
+                          double *best_cost, unsigned long long *n_evaluated, int32_t *order_ws, void *stream,
+                          bool keys_ready)
 {
     int rc = check_batch(batch, params);
     if (rc) return rc;
@@ -1874,7 +1887,8 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
         const dim3 grid(batch->B), block(threads);
         hipStream_t st = (hipStream_t)stream;
         if (order_ws && batch->B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
-            hipLaunchKernelGGL(sl_weight_narrow_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, a, order_ws);
+            if (!keys_ready)
+                hipLaunchKernelGGL(sl_weight_narrow_kernel, dim3((batch->B + 255) / 256), dim3(256), 0, st, a, order_ws);
             mp_order_launch(batch->B, order_ws, order_ws + batch->B, st);
             a.order = order_ws + batch->B;
         }

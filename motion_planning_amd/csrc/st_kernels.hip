@@ -670,7 +670,18 @@ struct RegDev {
     const int32_t *n_dy;
     double *s_down, *s_up;
     int32_t *n_reg, *status;
+    // whole replan only (null otherwise): the grid width of every scene and where the scene's
+    // weight bin for the ordered speed search goes (st_weight_kernel's value, from the counts
+    // this kernel has in hand)
+    const int32_t *key_n_s;
+    int32_t *key_out;
 };
+
+__device__ __forceinline__ int st_weight_bin(int n_s, int regs, int n_t)
+{
+    const double n = (double)max(n_s, 0);
+    return mp_weight_bin(n * n * (4.0 + (double)regs / (double)(n_t - 1)));
+}
 
 // One workgroup per scenario; the sampled path sits in LDS.  For every time
 // layer the obstacles are visited in the reference's order (statics, then
@@ -692,7 +703,7 @@ __global__ void st_regions_kernel(RegDev a)
         pl[k] = a.path_l[(size_t)b * a.p_max + k];
     }
     __syncthreads();
-    int overflow = 0;
+    int overflow = 0, regs_sum = 0;
     const int n_ob = n_st + n_dy;
     for (int i = 0; i < a.n_t; ++i) {
         if (tid == 0) base_sh = 0;
@@ -743,11 +754,17 @@ __global__ void st_regions_kernel(RegDev a)
             }
             __syncthreads();
         }
-        if (tid == 0) a.n_reg[(size_t)b * a.n_t + i] = min(base_sh, a.r_max);
+        if (tid == 0) {
+            a.n_reg[(size_t)b * a.n_t + i] = min(base_sh, a.r_max);
+            if (i >= 1) regs_sum += min(base_sh, a.r_max);
+        }
         __syncthreads();
     }
     overflow = __syncthreads_or(overflow);
-    if (tid == 0) a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
+    if (tid == 0) {
+        a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
+        if (a.key_out) a.key_out[b] = st_weight_bin(a.key_n_s[b], regs_sum, a.n_t);
+    }
 }
 
 
@@ -851,7 +868,7 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
     }
     __syncthreads();
     // per-layer lists in the reference's order: statics, then moving obstacles
-    int overflow = 0;
+    int overflow = 0, regs_sum = 0;
     const int n_ob = n_st + n_dy;
     for (int i = 0; i < n_t; ++i) {
         if (tid == 0) base_sh = 0;
@@ -880,11 +897,17 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
             }
             __syncthreads();
         }
-        if (tid == 0) a.n_reg[(size_t)b * n_t + i] = min(base_sh, a.r_max);
+        if (tid == 0) {
+            a.n_reg[(size_t)b * n_t + i] = min(base_sh, a.r_max);
+            if (i >= 1) regs_sum += min(base_sh, a.r_max);
+        }
         __syncthreads();
     }
     overflow = __syncthreads_or(overflow);
-    if (tid == 0) a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
+    if (tid == 0) {
+        a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
+        if (a.key_out) a.key_out[b] = st_weight_bin(a.key_n_s[b], regs_sum, n_t);
+    }
 }
 
 // A plan's time follows the square of its grid width (and its intervals): one thread per
@@ -893,10 +916,9 @@ __global__ void st_weight_kernel(int B, int n_t, const int32_t *n_s, const int32
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double n = (double)max(n_s[b], 0);
     int regs = 0;
     for (int i = 1; i < n_t; ++i) regs += max(n_reg[(size_t)b * n_t + i], 0);
-    key[b] = mp_weight_bin(n * n * (4.0 + (double)regs / (double)(n_t - 1)));
+    key[b] = st_weight_bin(n_s[b], regs, n_t);
 }
 
 // ---------------------------------------------------------------------------
@@ -915,7 +937,8 @@ static int st_launch_check(const char *what)
 static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
                         const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
                         double speed_lim, double ds, double dt, double *cost, int32_t *pre,
-                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream);
+                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream,
+                        bool keys_ready = false);
 
 extern "C" int mp_st_dp(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
                         const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
@@ -935,10 +958,21 @@ extern "C" int mp_st_dp_ordered(int32_t B, int32_t n_t, int32_t n_s_max, const i
                         path_s_ind, path_len, order_ws, stream);
 }
 
+// mp_st_dp_ordered for the whole replan, whose interval kernel has already left every scene's
+// weight bin in order_ws[0..B) (RegDev.key_out).
+int mp_st_dp_keyed(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
+                   const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
+                   double speed_lim, double ds, double dt, double *cost, int32_t *pre, int32_t *path_s_ind,
+                   int32_t *path_len, int32_t *order_ws, void *stream)
+{
+    return st_dp_launch(B, n_t, n_s_max, n_s, s_down, s_up, n_reg, r_max, cur_vel, speed_lim, ds, dt, cost, pre,
+                        path_s_ind, path_len, order_ws, stream, true);
+}
+
 static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *n_s, const double *s_down,
                         const double *s_up, const int32_t *n_reg, int32_t r_max, const double *cur_vel,
                         double speed_lim, double ds, double dt, double *cost, int32_t *pre,
-                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream)
+                        int32_t *path_s_ind, int32_t *path_len, int32_t *order_ws, void *stream, bool keys_ready)
 {
     if (B <= 0 || n_t < 2 || n_s_max <= 0 || r_max < 0) { mp_set_error("bad B/n_t/n_s_max/r_max"); return MP_E_BADARG; }
     if (!n_s || !n_reg || !cur_vel || !path_s_ind || !path_len || (r_max > 0 && (!s_down || !s_up))) {
@@ -967,7 +1001,8 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
         // widest grids first: weights -> order_ws[0..B), order -> order_ws[B..2B)
-        hipLaunchKernelGGL(st_weight_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_t, n_s, n_reg, order_ws);
+        if (!keys_ready)
+            hipLaunchKernelGGL(st_weight_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_t, n_s, n_reg, order_ws);
         mp_order_launch(B, order_ws, order_ws + B, st);
         a.order = order_ws + B;
     }
@@ -1003,7 +1038,8 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
                           const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
                           const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
                           int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
-                          int32_t *status, void *stream);
+                          int32_t *status, void *stream, const int32_t *key_n_s = nullptr,
+                          int32_t *key_out = nullptr);
 
 extern "C" int mp_st_regions(int32_t B, int32_t n_t, const double *path_s, const double *path_l,
                              const int32_t *n_path, int32_t p_max, const double *st_s, const double *st_l,
@@ -1021,7 +1057,7 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
                           const double *st_r, const int32_t *n_st, int32_t n_st_max, const double *dy_s,
                           const double *dy_l, const double *dy_r, const int32_t *n_dy, int32_t n_dy_max,
                           int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
-                          int32_t *status, void *stream)
+                          int32_t *status, void *stream, const int32_t *key_n_s, int32_t *key_out)
 {
     if (dy_fstride < n_t) { mp_set_error("fewer stored frames than time layers"); return MP_E_BADARG; }
     if (B <= 0 || n_t <= 0 || p_max <= 0 || r_max <= 0 || n_st_max < 0 || n_dy_max < 0) {
@@ -1038,7 +1074,7 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     if (lds > 128 * 1024) { mp_set_error("mp_st_regions: p_max too large"); return MP_E_UNSUPPORTED; }
     RegDev a{n_t, p_max, n_st_max, n_dy_max, r_max, dy_fstride, path_s, path_l, n_path, st_s, st_l, st_r,
              n_st_max > 0 ? n_st : nullptr, dy_s, dy_l, dy_r, n_dy_max > 0 ? n_dy : nullptr,
-             s_down, s_up, n_reg, status};
+             s_down, s_up, n_reg, status, key_n_s, key_n_s ? key_out : nullptr};
     int n_ob = n_st_max + n_dy_max;
     int threads = n_ob <= 64 ? 64 : (n_ob <= 128 ? 128 : 256);
     // every scan once, results kept in LDS, when they fit (MP_ST_REGIONS_ONCE=0: per-layer scans)
