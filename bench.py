@@ -21,8 +21,14 @@ The steps are timed twice (median of --reps timed blocks of K steps each).  Firs
 one stream with HIP events around every launch: the kernel times and rooflines.
 Then with the batch cut into --streams parts (default 2), part k on stream k: SL
 plan -> ST DP per part, no part waiting for another, so that the tail of one part's
-kernel runs beside the other part's; that is the headline (`value`), the one-stream
-rate is printed beside it (`value_one_stream`; --streams 1 makes it the headline).
+kernel runs beside the other part's.  `value` is the schedule --streams names (two
+parts by default, --streams 1 for one stream) whichever of them measured faster;
+`value_one_stream` and `value_two_streams` are always both printed, and
+`value_end_to_end` is the headline schedule with the host-to-device copy of the
+inputs in front of every step and the results handed over behind it.
+
+    python bench.py --gpus 1 --total-scenarios 65536   # the N = 1 anchor of the strong-scaling
+                                                        # curve (the workload --gpus N > 1 splits)
 
 Prints ONE JSON line (rank 0): plans/sec, the per-kernel rooflines, the same
 workload with the host->device copies of its inputs inside the step, the CPU oracle
@@ -180,10 +186,113 @@ def cpu_baseline(sc, n_sample, threads):
     return n_sample / dt, dt, res
 
 
-def check_lattice_parity(cpu_res, out, st):
+def single_plan_latencies(calls=200):
+    """One plan per call, the reference's own use (one replan per tick): launch to synchronised
+    result in microseconds (median of `calls` calls; the same call replayed as a HIP graph),
+    for the default SL lattice with 3 static obstacles (3 x 5 nodes), the default ST grid with
+    5 moving blocked intervals at 29 / 61 / 101 cells, and one whole replan of a scene with
+    256 obstacles.  Beside each: the C oracle on one host thread, and the reference's own
+    Python time as measured once in the build container (a constant; its source does not travel)."""
+    import torch
+    from motion_planning_amd import batch as mb, pipeline as pl
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+
+    def wall_us(fn, n):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return 1e6 * float(np.median(ts))
+
+    def graph_us(fn, n):
+        g = torch.cuda.CUDAGraph()
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            fn()
+        return wall_us(g.replay, n)
+
+    def cpu_us(fn, n):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return 1e6 * float(np.median(ts))
+
+    res = {"calls": calls, "timing": "time.perf_counter around call + device synchronisation, median; graph: the "
+                                     "same call captured once and replayed"}
+    # SL: 7 waypoints every 4.5 m, 3 static obstacles of radius 1 (the reference's default lattice)
+    s_layers = np.array([[8.0, 16.0, 28.0]])
+    l_row = np.linspace(-1.45, 1.45, 5)[None]
+    ob = np.array([[9.5, 0.2], [16.0, -1.0], [21.5, 1.2]])
+    sb = mb.SLBatch(s_layers, l_row, np.zeros((1, 2)), ob[None, :, 0], ob[None, :, 1], np.array([3], np.int32),
+                    np.array([1.0]))
+    out = mb.SLPlanOut(1, 3, 5, want_maps=False)
+    prm = mb.sl_params(n_l=5)
+    mb.sl_plan(sb, prm, out)
+    assert out.path_idx.cpu().tolist() == [[4, 4, 3]] and int(out.status[0]) == 1   # the reference's answer
+    s_map, l_map = np.repeat(s_layers[0][:, None], 5, axis=1), np.broadcast_to(l_row[0], (3, 5))
+    res["sl_default_3x5_3_obstacles"] = {
+        "entry_point": "mp_sl_plan", "gpu_us": wall_us(lambda: mb.sl_plan(sb, prm, out), calls),
+        "gpu_graph_us": graph_us(lambda: mb.sl_plan(sb, prm, out), calls),
+        "c_oracle_1_thread_us": cpu_us(lambda: orc.sl_find_path(s_map, l_map, 2, np.zeros(2), ob, 1.0), 50),
+        "reference_python_us": 62000.0 * 55 / 280,
+        "reference_python_note": "222 us per edge (0.062 s for the 280 edges of a 12-layer default lattice) x the 55 "
+                                 "edges of this 3-layer lattice"}
+    # ST: 11 time layers, 5 moving intervals, three grid widths
+    base = np.array([(12, 2), (20, 0), (6, 4), (25, -1), (15, 1)], dtype=np.float64)
+    st = {}
+    for s_end, ref_ms in ((28.0, 34.0), (60.0, 144.0), (100.0, 396.0)):
+        n_s = int(np.floor(s_end / 1.0)) + 1
+        s0 = base[:, 0] * (s_end / 28.0)
+        down = (s0[None, :] + base[None, :, 1] * 0.5 * np.arange(ST_N_T)[:, None])[None]
+        n_reg = np.full((1, ST_N_T), 5, np.int32)
+        args = (mb.to_dev(np.array([n_s]), torch.int32), mb.to_dev(down), mb.to_dev(down + 3.0),
+                mb.to_dev(n_reg, torch.int32), mb.to_dev(np.array([5.0])), SPEED_LIM)
+        o = mb.st_dp(*args, want_tables=False, n_s_max=n_s)
+        want = orc.st_find_speed(ST_N_T, n_s, down[0], down[0] + 3.0, n_reg[0], 5.0, SPEED_LIM)["path_s_ind"]
+        got = o["path_s_ind"][0, :int(o["path_len"][0])].cpu().numpy()
+        assert np.array_equal(got, want), "single ST plan differs from the oracle at %d cells" % n_s
+        fn = lambda: mb.st_dp(*args, want_tables=False, n_s_max=n_s, out=o)
+        st["%d_cells" % n_s] = {
+            "gpu_us": wall_us(fn, calls), "gpu_graph_us": graph_us(fn, calls),
+            "c_oracle_1_thread_us": cpu_us(lambda: orc.st_find_speed(ST_N_T, n_s, down[0], down[0] + 3.0, n_reg[0],
+                                                                      5.0, SPEED_LIM), 5),
+            "reference_python_us": 1e3 * ref_ms}
+    res["st_default_5_intervals"] = dict(st, entry_point="mp_st_dp")
+    # whole replan of one scene
+    sc = make_scenes(1)
+    dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
+    dev["line_vec"] = torch.zeros(1, dtype=torch.float64, device="cuda")
+    params = pl.default_params()
+    dims = pl.plan_dims(1, sc["knots_x"].shape[1], sc["st_pos"].shape[1], sc["dy_pos"].shape[1], n_l=5, m_max=200,
+                        params=params)
+    arena = pl.PlanArena(dims)
+    fn = lambda: pl.plan_scenes(dev, dims, params, arena)
+    res["whole_replan_1_scene_256_obstacles"] = {
+        "entry_point": "mp_plan_scenes", "gpu_us": wall_us(fn, calls), "gpu_graph_us": graph_us(fn, calls),
+        "c_oracle_1_thread_us": 1e6 * cpu_pipeline(sc, 1, 1)[1],
+        "reference_python_us": 0.6e6,
+        "reference_python_note": "0.4-0.8 s for SLMap alone on such a scene"}
+    return res
+
+
+def check_lattice_parity(cpu_res, out, st, sc):
     """GPU outputs of the timed run against the oracle's, scenario by scenario: outcome,
     lane per layer, layers relaxed and end cost of the SL plan; the ST plan's s indices.
-    A lane sequence may differ only where the two end costs tie within 1e-9 relative."""
+    A lane sequence may differ from the oracle's only where the two are a tie: the GPU's
+    sequence is then priced edge by edge with the oracle's own edge cost, accumulated in
+    the reference's order, and must come within 1e-9 relative of the oracle's end cost."""
+    from oracle import oracle as orc
     n = len(cpu_res)
     status = out.status[:n].cpu().numpy()
     path = out.path_idx[:n].cpu().numpy()
@@ -198,7 +307,17 @@ def check_lattice_parity(cpu_res, out, st):
         if r["found"]:
             assert abs(best[b] - r["best_cost"]) <= 1e-9 * abs(r["best_cost"]), "scenario %d: end cost differs" % b
             if not np.array_equal(path[b], r["path_idx"]):
-                ties += 1   # same end cost within 1e-9: a tie between two lane sequences
+                s_map = np.repeat(sc["s_layers"][b][:, None], N_L, axis=1)
+                l_map = np.broadcast_to(sc["l_row"][b], (N_S, N_L))
+                ob = np.stack([sc["ob_s"][b], sc["ob_l"][b]], 1)
+                cost = 0.0
+                for s in range(N_S):
+                    cost = orc.sl_cal_cost(s_map, l_map, int((N_L - 1) / 2), sc["ego"][b], ob, sc["ob_dist"][b],
+                                           s - 1, int(path[b, s - 1]) if s else 0, s, int(path[b, s]))[0] + cost
+                assert abs(cost - r["best_cost"]) <= 1e-9 * abs(r["best_cost"]), \
+                    "scenario %d: lane sequence differs from the oracle's and is no tie (%r against %r)" \
+                    % (b, cost, r["best_cost"])
+                ties += 1
         else:
             assert (path[b] == -1).all() and np.isnan(best[b])
         assert int(st_len[b]) == len(sp) and np.array_equal(st_path[b, :len(sp)], sp), \
@@ -257,12 +376,12 @@ class ResultGather:
     and drain() waits for everything (called before the clock stops).  Shards are padded
     to the largest one (rows), so ranks may hold different numbers of scenarios."""
 
-    def __init__(self, world, backend, B, rows, n_s, n_t, device="cuda"):
+    def __init__(self, world, backend, B, rows, n_s, n_t, device="cuda", active=None):
         import torch
         from motion_planning_amd import dist as mdist
         self.world, self.backend, self.mdist, self.B, self.rows = world, backend, mdist, B, rows
         self.k = 0
-        self.active = exchange_on(world)
+        self.active = exchange_on(world) if active is None else bool(active)   # False: the no-exchange leg
         if not self.active:
             return
         width = mdist.record_width(n_s, n_t)
@@ -371,6 +490,37 @@ class Job:
         if self.B <= 0:
             raise SystemExit("rank %d has no scenarios (total %d over %d ranks)" % (self.rank, self.total, self.world))
 
+    def describe(self):
+        """What the record needs to show that N ranks ran on N GPUs: group size and backend as
+        torch.distributed reports them, the collective library's version, and every rank's
+        device (index, name, PCI bus id) gathered to all ranks."""
+        import torch
+        import torch.distributed as dist
+        me = {"rank": self.rank, "pid": os.getpid(), "host": socket.gethostname()}
+        if self.gpu:
+            i = torch.cuda.current_device()
+            pr = torch.cuda.get_device_properties(i)
+            me.update(device_index=i, device_name=pr.name,
+                      pci_bus_id="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff,
+                                                     getattr(pr, "pci_device_id", 0)),
+                      uuid=str(getattr(pr, "uuid", "")))
+        d = {"world_size": self.world, "backend": None, "collective_library": None, "ranks": [me]}
+        if self.dist_on:
+            d["world_size"] = dist.get_world_size()
+            d["backend"] = dist.get_backend()
+            if self.backend == "nccl":
+                try:
+                    d["collective_library"] = "RCCL (torch.cuda.nccl.version) %s" % ".".join(
+                        str(v) for v in torch.cuda.nccl.version())
+                except Exception as e:   # version query is informational only
+                    d["collective_library"] = "unavailable: %s" % e
+            ranks = [None] * d["world_size"]
+            dist.all_gather_object(ranks, me)
+            d["ranks"] = ranks
+            devs = {(r.get("host"), r.get("pci_bus_id", r.get("pid"))) for r in ranks}
+            d["distinct_devices"] = len(devs) if self.gpu else 0
+        return d
+
     def fence(self):
         import torch
         import torch.distributed as dist
@@ -463,9 +613,19 @@ def launch_check(job):
             want = fake(lo, hi)
             assert torch.equal(u["path_idx"], want[0]) and torch.equal(u["status"], want[1])
             assert torch.equal(u["best_cost"], want[3]) and torch.equal(u["st_path"], want[4])
+    # the fields a multi-rank bench line carries about the exchange and the ranks, from the same
+    # code paths (no kernels here: a "step" is the exchange of the fake records alone)
+    gather_off = ResultGather(job.world, job.backend, job.B, job.rows, n_s, n_t, device="cpu", active=False)
+    sec_on = float(np.median(timed_blocks(job, lambda i: gather.submit(*mine), gather.drain, 3, 2)))
+    sec_off = float(np.median(timed_blocks(job, lambda i: gather_off.submit(*mine), gather_off.drain, 3, 2)))
+    who = job.describe()
     if job.rank == 0:
+        v, v_off = job.total * 3 / sec_on, job.total * 3 / sec_off
         print(json.dumps({"launch_check": "ok", "n_gpus": job.world, "total_scenarios": job.total,
-                          "scaling": job.scaling, "shards": shards, "backend": job.backend if job.dist_on else None}))
+                          "scaling": job.scaling, "shards": shards, "backend": job.backend if job.dist_on else None,
+                          "config": {"per_gpu_batch": job.B, "total_scenarios": job.total},
+                          "value": v, "value_no_exchange": v_off, "exchange_overhead_frac": 1.0 - v / v_off,
+                          "scenarios_rank0": job.B, "job": who}))
 
 
 # ---------------------------------------------------------------------------
@@ -550,9 +710,8 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     if rank != 0:
         return None
     one_sec = float(np.median(secs))
-    if split_secs and float(np.median(split_secs)) >= one_sec:
-        split_secs = None   # the parts gained nothing here (e.g. ranks sharing a card): one stream is the headline
-    if split_secs:
+    one_secs = secs
+    if split_secs:   # the schedule --streams names is the headline, whichever measured faster
         secs = split_secs
     sec = float(np.median(secs))
     ms = 1e3 * sec / steps
@@ -617,6 +776,9 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
                      "wait for one another" % (n_parts, n_parts)) if split_secs
                     else "one stream: one mp_plan_scenes call over all scenes per step",
         "value_one_stream": world * B * steps / one_sec, "ms_per_step_one_stream": 1e3 * one_sec / steps,
+        "value_two_streams": world * B * steps / float(np.median(split_secs)) if split_secs else None,
+        "ms_per_step_one_stream_min": 1e3 * min(one_secs) / steps,
+        "ms_per_step_one_stream_max": 1e3 * max(one_secs) / steps,
         "stage_times": "stage_ms and the rooflines: HIP events between the stages of one-stream calls over all scenes",
         "c2f_points_per_sec": world * n_pts * steps / sec,
         "status_fractions": {"planned": float((status == 1).mean()), "no_path": float((status == 0).mean()),
@@ -701,11 +863,18 @@ class H2DLoop:
     ST_KEYS = (("st_n_s", np.int32), ("down", np.float64), ("up", np.float64), ("n_reg", np.int32),
                ("cur_vel", np.float64))
 
-    def __init__(self, sc, prm, gather, n_parts=1):
+    def __init__(self, sc, prm, gather, n_parts=1, to_host=False):
         import torch
         from motion_planning_amd import batch as mb, dist as mdist
-        self.torch, self.mb, self.prm, self.gather = torch, mb, prm, gather
+        self.torch, self.mb, self.mdist, self.prm, self.gather = torch, mb, mdist, prm, gather
         B = sc["s_layers"].shape[0]
+        # to_host: the step also hands its results over -- through the exchange where one runs,
+        # else as packed records copied to pinned host memory behind the kernels of each part
+        self.rec_dev = self.rec_host = None
+        if to_host and not gather.active:
+            width = mdist.record_width(N_S, ST_N_T)
+            self.rec_dev = [torch.zeros((B, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.rec_host = [torch.zeros((B, width), dtype=torch.uint8).pin_memory() for _ in range(2)]
         # n_parts > 1: still one copy per step, then the kernels of part k on stream k over
         # that part's rows of the copied arrays (parts wait for the copy, not for one another)
         self.ranges = [mdist.shard_range(B, k, n_parts) for k in range(n_parts)]
@@ -756,6 +925,12 @@ class H2DLoop:
             with torch.cuda.stream(stream):
                 mb.sl_plan(p["sb"], self.prm, p["out"])
                 p["st"] = mb.st_dp(*p["st_in"], SPEED_LIM, want_tables=False, n_s_max=ST_N_S, out=p["st"])
+                if self.rec_dev is not None:
+                    k2 = self.k & 1
+                    self.mdist.pack_results(p["out"].path_idx, p["out"].status, p["out"].layers_done,
+                                            p["out"].best_cost, p["st"]["path_s_ind"], p["st"]["path_len"],
+                                            out=self.rec_dev[k2][p["lo"]:p["hi"]])
+                    self.rec_host[k2][p["lo"]:p["hi"]].copy_(self.rec_dev[k2][p["lo"]:p["hi"]], non_blocking=True)
                 p["done"].record(stream)
         if len(s["parts"]) == 1:
             p = s["parts"][0]
@@ -822,10 +997,11 @@ def bench_lattice(args, job):
     st_in = dict(n_s=mb.to_dev(sc["st_n_s"], torch.int32), s_down=mb.to_dev(sc["down"]), s_up=mb.to_dev(sc["up"]),
                  n_reg=mb.to_dev(sc["n_reg"], torch.int32), cur_vel=mb.to_dev(sc["cur_vel"]))
     gather = ResultGather(world, job.backend, B, job.rows, N_S, ST_N_T)
+    gather_off = ResultGather(world, job.backend, B, job.rows, N_S, ST_N_T, active=False)
     steps, reps = args.steps, args.reps
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
             torch.cuda.Event(enable_timing=True)) for _ in range(steps)] for _ in range(reps)]
-    state = dict(st=None, rep=-1)
+    state = dict(st=None, rep=-1, gather=gather)
 
     def step(i=None):
         e = ev[state["rep"]][i] if i is not None and state["rep"] >= 0 else None
@@ -839,7 +1015,8 @@ def bench_lattice(args, job):
         if e:
             e[2].record()
         st = state["st"]
-        gather.submit(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"], st["path_len"])
+        state["gather"].submit(out.path_idx, out.status, out.layers_done, out.best_cost, st["path_s_ind"],
+                               st["path_len"])
 
     for _ in range(args.warmup):
         step()
@@ -892,6 +1069,21 @@ def bench_lattice(args, job):
         assert torch.equal(split.cat(lambda p: p["st"]["path_len"]), st["path_len"])
         check_exchange()
 
+    # with an exchange in the step: the same steps of the headline schedule without it (same
+    # kernels, same shard per rank), so that the record separates what the exchange costs from
+    # what the batch size per GPU does
+    noex_secs = None
+    if job.dist_on:
+        if split_secs is not None:
+            split.gather = gather_off
+            noex_secs = timed_blocks(job, split.step, gather_off.drain, steps, reps)
+            split.gather = gather
+        else:
+            state["gather"] = gather_off
+            noex_secs = timed_blocks(job, step, gather_off.drain, steps, reps)
+            state["gather"] = gather
+    who = job.describe()
+
     # the step again with the host->device copies of its inputs inside (never `value`)
     h2d = None
     if args.h2d_reps > 0:
@@ -915,7 +1107,22 @@ def bench_lattice(args, job):
             torch.cuda.synchronize()
             assert torch.equal(loop2.cat(last, lambda p: p["out"].path_idx), out.path_idx)
             assert torch.equal(loop2.cat(last, lambda p: p["st"]["path_s_ind"]), st["path_s_ind"])
-        h2d = (hsecs, loop.bytes, hsecs2)
+        # end to end: the headline schedule with the copy of the inputs in front and the results
+        # handed over behind (exchange between the ranks, or records to pinned host memory)
+        e2e_parts = args.streams if split_secs is not None else 1
+        loop3 = H2DLoop(sc, prm, gather, e2e_parts, to_host=True)
+        for _ in range(max(2, args.warmup) + steps):
+            loop3.step()
+        gather.drain()
+        esecs = timed_blocks(job, loop3.step, gather.drain, steps, args.h2d_reps)
+        torch.cuda.synchronize()
+        if loop3.rec_host is not None:
+            u = mdist.unpack_results(loop3.rec_host[(loop3.k - 1) & 1], N_S, ST_N_T)
+            assert torch.equal(u["path_idx"], out.path_idx.cpu()) and torch.equal(u["st_path"], st["path_s_ind"].cpu())
+            assert torch.equal(u["status"], out.status.cpu())
+        else:
+            check_exchange()
+        h2d = (hsecs, loop.bytes, hsecs2, esecs, e2e_parts)
 
     # edges the fused kernel really prices (counting instance, outside the timed region)
     edges_eval = edges_serial = None
@@ -926,14 +1133,23 @@ def bench_lattice(args, job):
 
     if rank != 0:
         return None
+    # the headline is the schedule --streams names, whichever measured faster: two parts on two
+    # streams by default (when the shard is large enough to cut), the whole batch on one stream
+    # with --streams 1; both are always on the record
     one_sec = float(np.median(secs))
     one_secs = secs
-    if split_secs and float(np.median(split_secs)) >= one_sec:
-        split_secs = None   # the parts gained nothing here (e.g. ranks sharing a card): one stream is the headline
-    if split_secs:      # the headline is the schedule a caller would use; the kernels are timed alone
+    two_streams = split_secs is not None
+    if two_streams:
         secs = split_secs
     sec = float(np.median(secs))
     plans_per_s = job.total * steps / sec
+
+    def rate_stats(block_secs):
+        if block_secs is None:
+            return None
+        return {"median": job.total * steps / float(np.median(block_secs)), "min": job.total * steps / max(block_secs),
+                "max": job.total * steps / min(block_secs), "ms_per_step_median": 1e3 * float(np.median(block_secs)) / steps,
+                "blocks": len(block_secs)}
     k_samples = 4  # samples per edge at a 1.5 m layer gap and 0.5 m spacing
     # algorithmic work per unit, as the reference writes it (1 flop per add/mul/sqrt/compare)
     flop_edge = 45 + k_samples * (50 + 7 * N_OB)      # one SL edge
@@ -1001,7 +1217,11 @@ def bench_lattice(args, job):
                                "50 obstacles), every layer relaxed, + ST speed DP 11x97 with 5 blocked "
                                "intervals per layer; RCCL all-gather of results when n_gpus > 1"
                                % (job.total, world),
-                   "total_scenarios": job.total, "scenarios_rank0": B, "n_s": N_S, "n_l": N_L, "n_ob": N_OB,
+                   "total_scenarios": job.total, "scenarios_rank0": B, "per_gpu_batch": B,
+                   "shards": [(lambda span: span[1] - span[0])(mdist.shard_range(job.total, r, world))
+                              if job.scaling == "strong" else B for r in range(world)],
+                   "n_s": N_S, "n_l": N_L,
+                   "n_ob": N_OB,
                    "st_n_t": ST_N_T, "st_n_s": ST_N_S, "st_regions": ST_R, "early_exit": bool(args.early_exit),
                    "maps_written": bool(args.maps), "backend": job.backend if job.dist_on else None,
                    "parallelism": "scenario-sharded x%d" % world},
@@ -1009,9 +1229,12 @@ def bench_lattice(args, job):
         "lattice_edges_nominal_per_sec": world * edges_nominal / (sl_ms * 1e-3),
         "schedule": ("the batch in %d parts on %d streams, each part SL plan -> ST DP on its own stream; parts "
                      "never wait for one another (scenarios are independent), so one part's kernels fill the "
-                     "tail of the other's, also across steps" % (args.streams, args.streams)) if split_secs
+                     "tail of the other's, also across steps" % (args.streams, args.streams)) if two_streams
                     else "one stream: SL plan -> ST DP over the whole batch",
+        "schedule_chosen_by": "--streams %d (fixed by the flag, not by which schedule measured faster)" % args.streams,
         "value_one_stream": job.total * steps / one_sec,
+        "value_two_streams": job.total * steps / float(np.median(split_secs)) if two_streams else None,
+        "rates": {"one_stream": rate_stats(one_secs), "two_streams": rate_stats(split_secs)},
         "ms_per_step_one_stream": 1e3 * one_sec / steps,
         "ms_per_step_one_stream_min": 1e3 * min(one_secs) / steps,
         "kernel_times": "sl_kernel_ms / st_kernel_ms and every roofline: HIP events around each launch in the "
@@ -1020,25 +1243,44 @@ def bench_lattice(args, job):
         "roofline": dominant,
         "roofline_other": roof_st if dominant is roof_sl else roof_sl,
         "pmc_source": pmc.get("_source"),
+        "job": who,
     }
+    if noex_secs is not None:
+        # the same schedule, shard and kernels with the exchange switched off
+        v_noex = job.total * steps / float(np.median(noex_secs))
+        res["value_no_exchange"] = v_noex
+        res["exchange_overhead_frac"] = 1.0 - plans_per_s / v_noex
+        res["scenarios_rank0"] = B
+        res["rates"]["no_exchange"] = rate_stats(noex_secs)
     if h2d:
-        hsecs, nbytes, hsecs2 = h2d
+        hsecs, nbytes, hsecs2, esecs, e2e_parts = h2d
         one_hsec = float(np.median(hsecs))
-        hsec = min(one_hsec, float(np.median(hsecs2))) if hsecs2 else one_hsec
+        hsec = float(np.median(hsecs2)) if (hsecs2 and two_streams) else one_hsec
         res["value_with_h2d"] = job.total * steps / hsec
+        res["value_end_to_end"] = job.total * steps / float(np.median(esecs))
         res["h2d"] = {"ms_per_step": 1e3 * hsec / steps, "bytes_per_step_rank0": nbytes,
                       "copy_only_ms_at_63GBps": nbytes / 63e9 * 1e3,
                       "value_one_stream": job.total * steps / one_hsec,
+                      "value_two_streams": job.total * steps / float(np.median(hsecs2)) if hsecs2 else None,
+                      "rates": {"one_stream": rate_stats(hsecs), "two_streams": rate_stats(hsecs2),
+                                "end_to_end": rate_stats(esecs)},
                       "ms_per_step_one_stream": 1e3 * one_hsec / steps,
                       "ms_per_step_parts": 1e3 * float(np.median(hsecs2)) / steps if hsecs2 else None,
                       "ms_per_step_parts_min": 1e3 * min(hsecs2) / steps if hsecs2 else None,
                       "ms_per_step_one_stream_min": 1e3 * min(hsecs) / steps,
-                      "schedule": "one copy per step, then the kernels of two parts on two streams" if hsec < one_hsec
-                                  else "one copy per step, then the kernels on one stream",
+                      "schedule": "one copy per step, then the kernels of two parts on two streams"
+                                  if (hsecs2 and two_streams) else "one copy per step, then the kernels on one stream",
+                      "end_to_end": {"ms_per_step": 1e3 * float(np.median(esecs)) / steps, "parts": e2e_parts,
+                                     "results": "exchanged between the ranks (device-side packing + all-gather)"
+                                                if gather.active else
+                                                "packed on the device (one record per scenario) and copied to pinned "
+                                                "host memory behind each part's kernels"},
                       "note": "the same steps with the inputs copied from one pinned staging buffer inside them: one "
                               "copy per step on a copy stream into one of two device buffers, so the copy of step "
                               "i+1 runs beside the kernels of step i; both schedules of the kernels are timed (the "
-                              "parts wait for the copy, not for one another) and the faster median is value_with_h2d. "
+                              "parts wait for the copy, not for one another); value_with_h2d is the schedule "
+                              "--streams names, value_end_to_end that schedule with the results handed over as "
+                              "well (plans/s including the host-to-device copy and the result gather). "
                               "With two parts a timed block runs either at ms_per_step_parts_min (the copy hidden) "
                               "or about 0.2 ms slower (the copy exposed), block by block, so its median moves from "
                               "run to run; a copy per part instead of one per step ran slower than either (6.5 M)."}
@@ -1057,7 +1299,7 @@ def bench_lattice(args, job):
                                                             "edge -> ~25 min per 64x128x50 plan, plus 0.4 s per "
                                                             "ST plan of 101 cells"}}
         if not args.early_exit and not args.maps:
-            ties = check_lattice_parity(cres, out, st)
+            ties = check_lattice_parity(cres, out, st, sc)
             res["cpu_baseline"]["parity_checked"] = n
             res["cpu_baseline"]["parity_ties"] = ties
     return res
@@ -1089,6 +1331,8 @@ def main():
                     help="steps per timed block of the whole-replan leg attached to the lattice line (0 = skip)")
     ap.add_argument("--pipeline-scenes", type=int, default=4096, help="scenes per GPU of the whole-replan workload")
     ap.add_argument("--pipeline-cpu-sample", type=int, default=256)
+    ap.add_argument("--single-plan", type=int, default=200,
+                    help="calls per single-plan latency measurement (one plan per call; 0 = skip)")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise the launcher, the sharding and the result exchange only (CPU, gloo; no kernels)")
     args = ap.parse_args()
@@ -1109,6 +1353,8 @@ def main():
             pipe = bench_pipeline(args, job, args.pipeline_steps, 2, 5, args.pipeline_cpu_sample)
             if res is not None:
                 res["pipeline"] = pipe
+        if args.single_plan > 0 and job.world == 1 and res is not None:
+            res["single_plan"] = single_plan_latencies(args.single_plan)
     if job.rank == 0:
         print(json.dumps(res))
     job.close()

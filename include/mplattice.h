@@ -445,10 +445,13 @@ int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims,
  * MP_PLAN_STATIC_BYTES, and want_maps, are refused with MP_E_UNSUPPORTED.  All
  * calls on one GPU share that GPU's array: calls that overlap on one GPU (two
  * streams, two threads) race; calls on one stream are safe back to back.
+ * The first call on a GPU looks up that GPU's address of the array
+ * (hipGetSymbolAddress, which may load the code object and cannot be captured):
+ * make one ordinary call per GPU before capturing the entry point in a HIP graph.
  *   status   [B]         MP_PLAN_*
  *   n_points [B]         valid entries of x / y / speed (0 unless MP_PLAN_OK)
  *   x, y     [B][q_max]  path points in the robot frame (0 beyond n_points)
- *   speed    [B][q_max]  speed profile at those points, m/s */
+ *   speed    [B][q_max]  speed profile at those points, m/s (0 beyond n_points) */
 #define MP_PLAN_STATIC_BYTES (32u << 20)
 typedef struct mp_plan_result {
     int32_t *status, *n_points;

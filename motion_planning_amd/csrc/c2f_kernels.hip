@@ -814,11 +814,23 @@ extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, con
     return c2f_launch_check("mp_f2c_batch");
 }
 
-// The two fused stages of the whole replan (plan_glue.h); sizes were checked by the chain.
+// Spline kernels: dynamic LDS on top of the static arrays of curve_eval_scene (knots,
+// coefficients, running sums: below 12 KB) must stay within the 64 KB a workgroup gets here.
+#define CV_STATIC_LDS (12 * 1024)
+static int cv_lds_check(const char *what, const char *dim, int value, size_t lds)
+{
+    if (lds + CV_STATIC_LDS <= 64 * 1024) return MP_OK;
+    mp_set_error("%s: %s = %d needs %zu bytes of LDS per workgroup, more than the kernel can get", what, dim, value,
+                 lds + CV_STATIC_LDS);
+    return MP_E_UNSUPPORTED;
+}
+
+// The two fused stages of the whole replan (plan_glue.h).
 int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 {
     size_t lds = (size_t)a.p_max * (2 * sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
+    if (int rc = cv_lds_check("mp_plan_scenes (path spline)", "p_max", a.p_max, lds)) return rc;
     hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(a.p_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (path spline)");
 }
@@ -826,8 +838,12 @@ int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 int mp_plan_tail_stage(int32_t B, const PlanTailDev &a, void *stream)
 {
     size_t lds = (size_t)a.q_max * (2 * sizeof(double) + sizeof(int));
-    if (lds < (size_t)a.m_max * sizeof(double)) lds = (size_t)a.m_max * sizeof(double); // the arc-length table
+    const bool table_larger = lds < (size_t)a.m_max * sizeof(double);
+    if (table_larger) lds = (size_t)a.m_max * sizeof(double); // the arc-length table
     lds = (lds + 15) & ~(size_t)15;
+    if (int rc = cv_lds_check("mp_plan_scenes (speed profile and path points)", table_larger ? "m_max" : "q_max",
+                              table_larger ? a.m_max : a.q_max, lds))
+        return rc;
     hipLaunchKernelGGL(plan_tail_kernel, dim3(B), dim3(a.q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (speed profile and path points)");
 }
@@ -846,11 +862,11 @@ extern "C" int mp_curve_eval(int32_t B, const double *knots_t, const double *kno
         mp_set_error("null array");
         return MP_E_BADARG;
     }
-    if (q_max > 4096) { mp_set_error("mp_curve_eval: q_max > 4096"); return MP_E_UNSUPPORTED; }
     CvDev a{n_knots_max, q_max, mode, knots_t, knots_x, n_knots, vec, dt, query, n_query, out_t, out_x, out_dx,
             n_out, status};
     size_t lds = (size_t)q_max * (2 * sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
+    if (int rc = cv_lds_check("mp_curve_eval", "q_max", q_max, lds)) return rc;
     hipLaunchKernelGGL(curve_eval_kernel, dim3(B), dim3(q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_curve_eval");
 }

@@ -682,9 +682,13 @@ __global__ void plan_copy_out_kernel(PlanOutDev a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.B * a.q_max) return;
-    a.out.x[i] = a.final_x[i];
-    a.out.y[i] = a.final_y[i];
-    a.out.speed[i] = a.vv[i];
+    // slots behind a scene's last point read 0 (a scene that lost its plan in the last
+    // stage keeps converted points in the arena, but reports none)
+    const int b = i / a.q_max, j = i - b * a.q_max;
+    const bool live = a.status[b] == MP_PLAN_OK && j < a.n_final[b];
+    a.out.x[i] = live ? a.final_x[i] : 0.0;
+    a.out.y[i] = live ? a.final_y[i] : 0.0;
+    a.out.speed[i] = live ? a.vv[i] : 0.0;
     if (i < a.B) {
         const int st = a.status[i];
         a.out.status[i] = st;

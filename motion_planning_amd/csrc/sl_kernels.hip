@@ -988,7 +988,11 @@ __global__ void sl_plan_kernel(SlDev a)
         if (s == 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer 2
         const bool next_local = s >= 1 && s + 1 < n_s && (s == 1 ? is_local(c_top, nxt.w_inv) : locL[s + 1] != 0);
         if (is_target) {
-            if (!local) idx8[(size_t)s * n_l + tid] = (unsigned char)bj; // a layer without exchange keeps every lane
+            // (a layer without exchange keeps every lane: bj == tid.  It is stored all the same:
+            // whether the backtrack reads the row is decided by locL, whose bound is not the one
+            // `local` was derived from, and the two may disagree by a rounding error's width.
+            // Only the layers of the run loop above, which locL and runL agree on, skip the store.)
+            idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
             const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
             if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;

@@ -980,6 +980,9 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         return MP_E_BADARG;
     }
     if (!(ds > 0) || !(dt > 0) || !(speed_lim > 0)) { mp_set_error("ds, dt, speed_lim must be positive"); return MP_E_BADARG; }
+    // n_s_max: the history word holds 8*(pp-2p) and 8*(3pp-ppp-3p) as signed 16-bit halves and
+    // fire distances are u16 values of 16*d, so 24*n_s_max must stay below 32768 whatever LDS holds
+    static_assert(24 * 1024 < 32768, "history word / fire distance encoding");
     if (n_t > 64 || n_s_max > 1024 || r_max > 256) {
         mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 256");
         return MP_E_UNSUPPORTED;

@@ -86,6 +86,12 @@ def test_bench_launches_its_own_ranks(flags, total, shards):
     assert r["launch_check"] == "ok" and r["n_gpus"] == 2 and r["total_scenarios"] == total
     assert r["shards"] == shards and r["backend"] == "gloo"
     assert r["scaling"] == ("weak" if "--scenarios" in flags else "strong")
+    # what a multi-rank line says about the exchange and about who took part
+    assert r["value"] > 0 and r["value_no_exchange"] > 0 and r["exchange_overhead_frac"] < 1.0
+    assert r["scenarios_rank0"] == shards[0] == r["config"]["per_gpu_batch"]
+    job = r["job"]
+    assert job["world_size"] == 2 and job["backend"] == "gloo"
+    assert [q["rank"] for q in job["ranks"]] == [0, 1] and len({q["pid"] for q in job["ranks"]}) == 2
 
 
 def test_shard_range_covers_everything():
