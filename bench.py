@@ -115,7 +115,29 @@ def make_scenes(B, n_st=192, n_dy=64, seed=5):
     dy_pos = np.stack(frames, 2)
     return dict(knots_x=kx, knots_y=ky, n_knots=nk, ego_vel=ego_vel, st_pos=st_pos,
                 st_rad=np.full((B, n_st), 0.8), n_st=np.full(B, n_st, np.int32), dy_pos=dy_pos,
-                dy_rad=np.full((B, n_dy), 0.8), n_dy=np.full(B, n_dy, np.int32))
+                dy_rad=np.full((B, n_dy), 0.8), n_dy=np.full(B, n_dy, np.int32), dy_vel=vel)
+
+
+def to_world_frame(sc, seed=11):
+    """The scenes of make_scenes as a caller of PlannerInterface.run_step holds them: a random
+    ego pose (R, t) per scene, waypoints and obstacles (statics first, then the moving ones
+    with their velocity) in the world frame.  Every obstacle lies ahead of the ego."""
+    B = sc["knots_x"].shape[0]
+    rng = np.random.default_rng(seed)
+    th = rng.uniform(-np.pi, np.pi, B)
+    rot = np.stack([np.stack([np.cos(th), -np.sin(th)], 1), np.stack([np.sin(th), np.cos(th)], 1)], 1)   # [B, 2, 2]
+    trans = rng.uniform(-300, 300, (B, 2))
+
+    def turn(p):        # R p for [B, n, 2]
+        return np.einsum("bij,bnj->bni", rot, p)
+
+    way = turn(np.stack([sc["knots_x"], sc["knots_y"]], 2)) + trans[:, None, :]
+    ob_pos = turn(np.concatenate([sc["st_pos"], sc["dy_pos"][:, :, 0, :]], 1)) + trans[:, None, :]
+    ob_vel = turn(np.concatenate([np.zeros_like(sc["st_pos"]), sc["dy_vel"]], 1))
+    return dict(rot=rot.reshape(B, 4), trans=trans, ego_vel_w=np.einsum("bij,bj->bi", rot, sc["ego_vel"]),
+                way_xy=way, n_way=sc["n_knots"].astype(np.int32), ob_pos=ob_pos, ob_vel=ob_vel,
+                ob_rad=np.concatenate([sc["st_rad"], sc["dy_rad"]], 1),
+                n_ob=(sc["n_st"] + sc["n_dy"]).astype(np.int32))
 
 
 # ---------------------------------------------------------------------------
@@ -640,17 +662,19 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     B = args.pipeline_scenes
     world, rank = job.world, job.rank
     sc = make_scenes(B, seed=5 + rank)
-    dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
-    dev["line_vec"] = torch.zeros(B, dtype=torch.float64, device="cuda")
+    # the scenes as PlannerInterface.run_step receives them: world frame, an ego pose per scene
+    wsc = to_world_frame(sc, seed=11 + rank)
+    wdev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in wsc.items()}
+    n_st_max, n_dy_max = sc["st_pos"].shape[1], sc["dy_pos"].shape[1]
+    ignore = 1e9   # RobotMap's 20 m obstacle range lifted: every obstacle along the line takes part
     params = pl.default_params()
-    dims = pl.plan_dims(B, sc["knots_x"].shape[1], sc["st_pos"].shape[1], sc["dy_pos"].shape[1], n_l=5, m_max=200,
-                        params=params)
+    dims = pl.plan_dims(B, sc["knots_x"].shape[1], n_st_max, n_dy_max, n_l=5, m_max=200, params=params, world=True)
     arena = pl.PlanArena(dims)
     a = arena.arrays
     gather = ResultGather(world, job.backend, B, B, dims.n_s_max, dims.n_t)
 
     def step(_i=None):
-        pl.plan_scenes(dev, dims, params, arena)
+        pl.plan_world_scenes(wdev, dims, params, arena, ignore_dist=ignore)
         gather.submit(a["path_idx"], a["sl_status"], a["layers_done"], a["best_cost"], a["st_path_s_ind"],
                       a["st_path_len"])
 
@@ -670,16 +694,16 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
         parts = []
         for k in range(n_parts):
             lo, hi = mdist.shard_range(B, k, n_parts)
-            pdims = pl.plan_dims(hi - lo, sc["knots_x"].shape[1], sc["st_pos"].shape[1], sc["dy_pos"].shape[1],
-                                 n_l=5, m_max=200, params=params)
-            parts.append(dict(lo=lo, hi=hi, dev={kk: v[lo:hi].contiguous() for kk, v in dev.items()}, dims=pdims,
+            pdims = pl.plan_dims(hi - lo, sc["knots_x"].shape[1], n_st_max, n_dy_max, n_l=5, m_max=200, params=params,
+                                 world=True)
+            parts.append(dict(lo=lo, hi=hi, dev={kk: v[lo:hi].contiguous() for kk, v in wdev.items()}, dims=pdims,
                               arena=pl.PlanArena(pdims), stream=shared_stream("part%d" % k)))
         torch.cuda.synchronize()
 
         def split_step(_i=None):
             for p in parts:
                 with torch.cuda.stream(p["stream"]):
-                    pl.plan_scenes(p["dev"], p["dims"], params, p["arena"])
+                    pl.plan_world_scenes(p["dev"], p["dims"], params, p["arena"], ignore_dist=ignore)
             gather.submit_parts([(p["lo"], p["hi"], p["stream"],
                                   tuple(p["arena"].arrays[kk] for kk in ("path_idx", "sl_status", "layers_done",
                                                                          "best_cost", "st_path_s_ind", "st_path_len")))
@@ -690,7 +714,7 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
         gather.drain()
         split_secs = timed_blocks(job, split_step, gather.drain, steps, reps)
         torch.cuda.synchronize()
-        for kk in ("status", "n_final", "path_idx", "st_path_s_ind", "final_x", "final_y", "vv"):
+        for kk in ("status", "n_final", "path_idx", "st_path_s_ind", "final_x", "final_y", "vv", "world_x", "world_y"):
             got = torch.cat([p["arena"].arrays[kk] for p in parts])
             assert torch.equal(got, a[kk]) or (got.is_floating_point() and
                                                torch.equal(got.nan_to_num(), a[kk].nan_to_num())), kk
@@ -701,10 +725,25 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     assert set(np.unique(status)) <= {1, 0, -4}, "unexpected scene status %s" % np.unique(status)
     n_final = a["n_final"].cpu().numpy()
     assert (n_final[status == 1] >= 2).all()
+    # every obstacle of every scene was kept by the ingestion, in its class
+    assert torch.equal(a["w_n_st"].cpu(), torch.as_tensor(sc["n_st"])) and torch.equal(a["w_n_dy"].cpu(),
+                                                                                       torch.as_tensor(sc["n_dy"]))
+    # the chain alone, from the robot-frame scene the ingestion left in the arena (what this leg
+    # timed before it started from world-frame scenes)
+    rdims = pl.plan_dims(B, sc["knots_x"].shape[1], n_st_max, n_dy_max, n_l=5, m_max=200, params=params)
+    rarena = pl.PlanArena(rdims)
+    rdev = dict(knots_x=a["w_knots_x"], knots_y=a["w_knots_y"], n_knots=wdev["n_way"], ego_vel=a["w_ego_vel"],
+                st_pos=a["w_st_pos"], st_rad=a["w_st_rad"], n_st=a["w_n_st"], dy_pos=a["w_dy_pos"],
+                dy_rad=a["w_dy_rad"], n_dy=a["w_n_dy"], line_vec=torch.zeros(B, dtype=torch.float64, device="cuda"))
+    pl.plan_scenes(rdev, rdims, params, rarena)
+    robot_secs = timed_blocks(job, lambda i: pl.plan_scenes(rdev, rdims, params, rarena), lambda: None, steps,
+                              max(1, reps // 2))
+    for kk in ("status", "n_final", "final_x", "final_y", "vv"):
+        assert torch.equal(rarena.arrays[kk].nan_to_num(), a[kk].nan_to_num()), kk
     # per-stage durations from HIP events between the stages (three calls, averaged)
     stage = None
     for _ in range(3):
-        _, ms = pl.plan_scenes_timed(dev, dims, params, arena)
+        _, ms = pl.plan_world_scenes_timed(wdev, dims, params, arena, ignore_dist=ignore)
         stage = ms if stage is None else [(n, t0 + t1) for (n, t0), (_, t1) in zip(stage, ms)]
     stage = [(n, t / 3.0) for n, t in stage]
     if rank != 0:
@@ -725,7 +764,7 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     flop_st = float(np.sum(ok * (st_n_s * (30 + 9 * n_reg[:, 1]) +
                                  np.sum(per_layer_edges[:, None] * (30 + 9 * n_reg[:, 2:]), axis=1))))
     M = a["tab_m"].cpu().numpy().astype(np.float64)
-    pts = sc["n_st"] + 11.0 * sc["n_dy"] + 1
+    pts = sc["n_st"] + float(dims.n_frames) * sc["n_dy"] + 1
     flop_fe = float(np.sum((status != -5) * pts * (7 * M + 40)))
     pmc = load_pmc("pmc_pipeline_latest.json")
 
@@ -760,8 +799,8 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     roofs.append(sl_entry)
     n_pts = B * (sc["st_pos"].shape[1] + sc["dy_pos"].shape[1] * 11 + 1)
     res = {
-        "metric": "full replan plans/sec (Cartesian->Frenet + SL path DP + ST speed DP + speed profile + path in "
-                  "the robot frame)",
+        "metric": "full replan plans/sec (world-frame scene in: ego-frame transform and obstacle filtering + "
+                  "Cartesian->Frenet + SL path DP + ST speed DP + speed profile + path in the robot and world frames)",
         "value": world * B * steps / sec, "unit": "plans/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": ms, "timed_reps": reps,
         "ms_per_step_min": 1e3 * min(secs) / steps, "ms_per_step_max": 1e3 * max(secs) / steps,
@@ -769,16 +808,21 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "full pipeline: %d scenes/GPU, curved reference lines of 16-21 knots, 192 static + "
                                "64 moving obstacles (897 points to Frenet per scene), default lattice (5 lanes, "
-                               "layers every 8 m), default ST grid; one mp_plan_scenes call per step" % B,
+                               "layers every 8 m), default ST grid; scenes given in the world frame with an ego "
+                               "pose each, one mp_plan_world_scenes call per step" % B,
                    "scenarios_per_gpu": B, "n_l": 5, "n_st": 192, "n_dy": 64,
                    "parallelism": "scenario-sharded x%d" % world},
-        "schedule": ("the scenes in %d parts on %d streams, one mp_plan_scenes call per part and step, parts never "
-                     "wait for one another" % (n_parts, n_parts)) if split_secs
-                    else "one stream: one mp_plan_scenes call over all scenes per step",
+        "schedule": ("the scenes in %d parts on %d streams, one mp_plan_world_scenes call per part and step, parts "
+                     "never wait for one another" % (n_parts, n_parts)) if split_secs
+                    else "one stream: one mp_plan_world_scenes call over all scenes per step",
         "value_one_stream": world * B * steps / one_sec, "ms_per_step_one_stream": 1e3 * one_sec / steps,
         "value_two_streams": world * B * steps / float(np.median(split_secs)) if split_secs else None,
         "ms_per_step_one_stream_min": 1e3 * min(one_secs) / steps,
         "ms_per_step_one_stream_max": 1e3 * max(one_secs) / steps,
+        "value_robot_frame_one_stream": world * B * steps / float(np.median(robot_secs)),
+        "ms_per_step_robot_frame_one_stream": 1e3 * float(np.median(robot_secs)) / steps,
+        "robot_frame": "mp_plan_scenes on the robot-frame scenes the ingestion left in the arena: the chain "
+                       "without its first and last step, one stream, same results bit for bit",
         "stage_times": "stage_ms and the rooflines: HIP events between the stages of one-stream calls over all scenes",
         "c2f_points_per_sec": world * n_pts * steps / sec,
         "status_fractions": {"planned": float((status == 1).mean()), "no_path": float((status == 0).mean()),
@@ -790,8 +834,17 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     if cpu_sample > 0 and world == 1:  # the CPU leg belongs to the one-GPU run only
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         n = min(cpu_sample, B)
-        v, dt, cres = cpu_pipeline(sc, n, threads)
-        fx, fy, vv = (a[k][:n].cpu().numpy() for k in ("final_x", "final_y", "vv"))
+        # the oracle plans the robot-frame scenes the GPU's ingestion produced (that kernel is held
+        # bit-equal to the reference's RobotMap by the world-frame fixtures of the tests); the way
+        # back to the world frame is checked against R p + t
+        sc_in = {k: a[w][:n].cpu().numpy() for k, w in (("knots_x", "w_knots_x"), ("knots_y", "w_knots_y"),
+                                                         ("ego_vel", "w_ego_vel"), ("st_pos", "w_st_pos"),
+                                                         ("st_rad", "w_st_rad"), ("dy_pos", "w_dy_pos"),
+                                                         ("dy_rad", "w_dy_rad"))}
+        sc_in["n_knots"] = wsc["n_way"][:n]
+        v, dt, cres = cpu_pipeline(sc_in, n, threads)
+        fx, fy, vv, gx, gy = (a[k][:n].cpu().numpy() for k in ("final_x", "final_y", "vv", "world_x", "world_y"))
+        rot, trans = wsc["rot"].reshape(-1, 2, 2), wsc["trans"]
         for b, r in enumerate(cres):
             assert (r is not None) == (status[b] == 1), "scene %d: planned/not planned differs from the oracle" % b
             if r is not None:
@@ -799,9 +852,11 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
                 assert m == n_final[b], "scene %d: number of path points differs" % b
                 np.testing.assert_allclose(np.stack([fx[b, :m], fy[b, :m]], 1), r[0], rtol=1e-9, atol=1e-8)
                 np.testing.assert_allclose(vv[b, :m], r[1], rtol=1e-9, atol=1e-12)
+                np.testing.assert_allclose(np.stack([gx[b, :m], gy[b, :m]], 1), r[0] @ rot[b].T + trans[b], rtol=1e-9,
+                                           atol=1e-7)
         res["cpu_baseline"] = {"value": v, "unit": "plans/s", "cores": threads, "kind": "port",
-                               "sample": "first %d scenes of the same batch, whole replan, C oracle driven from "
-                                         "Python, %d threads, %.1f s" % (n, threads, dt),
+                               "sample": "first %d scenes of the same batch, whole replan from the robot-frame scene "
+                                         "on, C oracle driven from Python, %d threads, %.1f s" % (n, threads, dt),
                                "parity_checked": n}
     return res
 
@@ -869,11 +924,11 @@ class H2DLoop:
         self.torch, self.mb, self.mdist, self.prm, self.gather = torch, mb, mdist, prm, gather
         B = sc["s_layers"].shape[0]
         # to_host: the step also hands its results over -- through the exchange where one runs,
-        # else as packed records copied to pinned host memory behind the kernels of each part
+        # else as packed records that the packing kernel of each part writes into pinned host memory
         self.rec_dev = self.rec_host = None
         if to_host and not gather.active:
             width = mdist.record_width(N_S, ST_N_T)
-            self.rec_dev = [torch.zeros((B, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.rec_dev = True
             self.rec_host = [torch.zeros((B, width), dtype=torch.uint8).pin_memory() for _ in range(2)]
         # n_parts > 1: still one copy per step, then the kernels of part k on stream k over
         # that part's rows of the copied arrays (parts wait for the copy, not for one another)
@@ -929,8 +984,7 @@ class H2DLoop:
                     k2 = self.k & 1
                     self.mdist.pack_results(p["out"].path_idx, p["out"].status, p["out"].layers_done,
                                             p["out"].best_cost, p["st"]["path_s_ind"], p["st"]["path_len"],
-                                            out=self.rec_dev[k2][p["lo"]:p["hi"]])
-                    self.rec_host[k2][p["lo"]:p["hi"]].copy_(self.rec_dev[k2][p["lo"]:p["hi"]], non_blocking=True)
+                                            out=self.rec_host[k2][p["lo"]:p["hi"]])   # stored over PCIe by the kernel
                 p["done"].record(stream)
         if len(s["parts"]) == 1:
             p = s["parts"][0]
@@ -1273,8 +1327,8 @@ def bench_lattice(args, job):
                       "end_to_end": {"ms_per_step": 1e3 * float(np.median(esecs)) / steps, "parts": e2e_parts,
                                      "results": "exchanged between the ranks (device-side packing + all-gather)"
                                                 if gather.active else
-                                                "packed on the device (one record per scenario) and copied to pinned "
-                                                "host memory behind each part's kernels"},
+                                                "packed on the device (one record per scenario) straight into pinned "
+                                                "host memory, behind each part's kernels"},
                       "note": "the same steps with the inputs copied from one pinned staging buffer inside them: one "
                               "copy per step on a copy stream into one of two device buffers, so the copy of step "
                               "i+1 runs beside the kernels of step i; both schedules of the kernels are timed (the "

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MP_VERSION 123
+#define MP_VERSION 124
 
 /* host-side return codes */
 #define MP_OK 0
@@ -388,6 +388,8 @@ typedef struct mp_plan_dims {
     int32_t r_max;      /* blocked intervals per time layer                           */
     int32_t q_max;      /* speed-profile samples ((n_t - 1) * 5 + 2)                  */
     int32_t want_maps;  /* 1: keep SL cost_map / index_map and ST cost / pre tables   */
+    int32_t world;      /* 1: the arena also holds the ingested robot-frame scene and the
+                           final path in the world frame (mp_plan_world_scenes)       */
 } mp_plan_dims;
 
 /* Constants of the reference's planner stack; mp_plan_default_params fills in
@@ -429,10 +431,49 @@ int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const
  * writes each stage's duration in milliseconds to stage_ms[MP_PLAN_N_STAGES]
  * (HOST memory); mp_plan_stage_name(i) names stage i.  Results in the arena as
  * from mp_plan_scenes.  Not for graph capture (creates and waits on events). */
-#define MP_PLAN_N_STAGES 8
+#define MP_PLAN_N_STAGES 9
 const char *mp_plan_stage_name(int32_t i);
 int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                          void *arena, int64_t arena_bytes, void *stream, float *stage_ms);
+
+/* ---- whole replan from world-frame scenes ----------------------------------
+ * Replaces PlannerInterface.run_step from its inputs to its outputs
+ * (Planning/Interface/planner_interface.py:35-95): coor_trans (:98-131, the ego
+ * pose as rotation R and translation t, RobotMap.add_robot / add_ref_line /
+ * add_obstacle, robot_map.py:25-68) -> path_plan -> speed_plan ->
+ * sl_map.path_convert -> robot_map.path_convert (robot_map.py:84-91), for B scenes
+ * in one enqueue: mp_scene_ingest's kernel writes the robot-frame scene into the
+ * arena, the chain of mp_plan_scenes runs on it, and its last stage stores every
+ * path point in the world frame as well.
+ * dims: world = 1; n_knots_max = waypoint slots per scene; n_st_max / n_dy_max =
+ * capacity for KEPT static / moving obstacles (a scene that keeps more gets status
+ * MP_PLAN_E_CAPACITY); ob_max obstacle slots per scene in the input.
+ * Additional arrays of the arena (mp_plan_array_info): w_knots_x, w_knots_y,
+ * w_ego_vel, w_st_pos, w_st_rad, w_n_st, w_dy_pos, w_dy_rad, w_n_dy (the scene as
+ * mp_scene_batch describes it), w_status, and world_x / world_y [B][q_max], the
+ * path of array final_x / final_y as R p + t (0 beyond n_final). */
+typedef struct mp_world_batch {
+    const double *rot;       /* [B][4] row-major ego rotation R                       */
+    const double *trans;     /* [B][2] ego position t                                 */
+    const double *ego_vel_w; /* [B][2]                                                */
+    const double *way_xy;    /* [B][n_knots_max][2] lane waypoints ahead              */
+    const int32_t *n_way;    /* [B]                                                   */
+    const double *line_vec;  /* [B] end slope of the line, or NULL (0)                */
+    const double *ob_pos;    /* [B][ob_max][2]                                        */
+    const double *ob_vel;    /* [B][ob_max][2]                                        */
+    const double *ob_rad;    /* [B][ob_max]                                           */
+    const int32_t *n_ob;     /* [B]                                                   */
+    int32_t ob_max;
+    int32_t reserved;
+    double ignore_dist;      /* 20 (robot_map.py:19)                                  */
+    double frame_dt;         /* 0.5: spacing of the predicted frames (obstacle.py:48) */
+} mp_world_batch;
+int mp_plan_world_scenes(const mp_world_batch *world, const mp_plan_dims *dims, const mp_plan_params *params,
+                         void *arena, int64_t arena_bytes, void *stream);
+/* mp_plan_scenes_timed for world-frame scenes (the ingestion is stage 1). */
+int mp_plan_world_scenes_timed(const mp_world_batch *world, const mp_plan_dims *dims,
+                               const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream,
+                               float *stage_ms);
 
 /* ---- whole replan without a caller-owned arena ------------------------------
  * No counterpart in the reference.  For callers that cannot allocate device

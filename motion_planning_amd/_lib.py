@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmplattice.so")
 
 MP_OK = 0
-MP_VERSION = 123   # MP_VERSION of include/mplattice.h this binding was written for
+MP_VERSION = 124   # MP_VERSION of include/mplattice.h this binding was written for
 MP_SL_FOUND, MP_SL_NOT_FOUND, MP_SL_E_EMPTY_EDGE, MP_SL_E_CAPACITY, MP_SL_SKIPPED = 1, 0, -2, -3, -4
 MP_ST_OK, MP_ST_E_CAPACITY = 1, -3
 MP_RL_OK, MP_RL_E_INDEX, MP_RL_E_CAPACITY = 1, -1, -3
@@ -44,7 +44,14 @@ class SceneBatch(C.Structure):       # mp_scene_batch
 
 class PlanDims(C.Structure):         # mp_plan_dims
     _fields_ = [(n, C.c_int32) for n in ("B", "n_knots_max", "n_st_max", "n_dy_max", "n_frames", "n_l", "m_max",
-                                         "n_s_max", "p_max", "n_t", "st_n_s_max", "r_max", "q_max", "want_maps")]
+                                         "n_s_max", "p_max", "n_t", "st_n_s_max", "r_max", "q_max", "want_maps",
+                                         "world")]
+
+
+class WorldBatch(C.Structure):       # mp_world_batch
+    _fields_ = [(n, _vp) for n in ("rot", "trans", "ego_vel_w", "way_xy", "n_way", "line_vec", "ob_pos", "ob_vel",
+                                   "ob_rad", "n_ob")] + [("ob_max", C.c_int32), ("reserved", C.c_int32),
+                                                         ("ignore_dist", C.c_double), ("frame_dt", C.c_double)]
 
 
 class PlanResult(C.Structure):       # mp_plan_result
@@ -52,7 +59,7 @@ class PlanResult(C.Structure):       # mp_plan_result
 
 
 MP_PLAN_STATIC_BYTES = 32 << 20
-MP_PLAN_N_STAGES = 8
+MP_PLAN_N_STAGES = 9
 
 
 class PlanParams(C.Structure):       # mp_plan_params
@@ -102,6 +109,10 @@ SIGNATURES = {
                                        C.c_int64, _vp, C.POINTER(C.c_float)]),
     "mp_plan_scenes": (C.c_int, [C.POINTER(SceneBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp, C.c_int64,
                                  _vp]),
+    "mp_plan_world_scenes": (C.c_int, [C.POINTER(WorldBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp,
+                                       C.c_int64, _vp]),
+    "mp_plan_world_scenes_timed": (C.c_int, [C.POINTER(WorldBatch), C.POINTER(PlanDims), C.POINTER(PlanParams), _vp,
+                                             C.c_int64, _vp, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -420,7 +420,20 @@ struct F2cDev {
     // evaluations before this kernel reported
     int32_t *plan_status;
     const int32_t *prof_status, *final_status, *n_prof;
+    // whole replan from world-frame scenes only (null otherwise): the ego pose of every scene
+    // and where the points go in the world frame, R p + t (robot_map.py:84-91)
+    const double *rot, *trans;
+    double *wx, *wy;
 };
+
+// GeneralConverter.robot_to_world (general_converter.py:19-22), products accumulated as
+// robot_to_world_kernel does
+__device__ __forceinline__ void f2c_to_world(const F2cDev &a, const int p, const int b, double px, double py)
+{
+    const double *r = a.rot + 4 * (size_t)b;
+    a.wx[p] = __dadd_rn(fma(r[1], py, __dmul_rn(r[0], px)), a.trans[2 * b]);
+    a.wy[p] = __dadd_rn(fma(r[3], py, __dmul_rn(r[2], px)), a.trans[2 * b + 1]);
+}
 
 // One thread per point (cartesian_frenet_conversion.py:55-60 with get_rxy
 // :72-86): the first table abscissa whose arc length reaches s; past the table
@@ -441,6 +454,7 @@ __device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int 
     }
     if (!a.pt_scn && a.n_valid && p - b * a.pts_per_scn >= a.n_valid[b]) {
         a.x[p] = a.y[p] = 0.0;
+        if (a.wx) a.wx[p] = a.wy[p] = 0.0;
         return;
     }
     const int n = a.n_inv[b];
@@ -460,12 +474,15 @@ __device__ __forceinline__ void f2c_one(const F2cDev &a, const int p, const int 
     }
     if (n <= 0) {
         a.x[p] = a.y[p] = __builtin_nan("");
+        if (a.wx) a.wx[p] = a.wy[p] = __builtin_nan("");
         return;
     }
     const size_t o = (size_t)b * a.m_max + k;
     const double th = a.inv_theta[o];
-    a.x[p] = a.inv_x[o] - l * sin(th);
-    a.y[p] = a.inv_y[o] + l * cos(th);
+    const double px = a.inv_x[o] - l * sin(th), py = a.inv_y[o] + l * cos(th);
+    a.x[p] = px;
+    a.y[p] = py;
+    if (a.wx) f2c_to_world(a, p, b, px, py);
 }
 
 __global__ void f2c_kernel(F2cDev a)
@@ -742,7 +759,7 @@ __global__ void plan_tail_kernel(PlanTailDev a)
     __syncthreads();
     F2cDev f{0, a.m_max, a.final_s, a.final_l, nullptr, a.q_max, a.n_final, a.inv_x, a.inv_s, a.inv_y,
              a.inv_theta, nullptr, a.n_inv, a.final_x, a.final_y, a.status, a.prof_status, a.final_status,
-             a.n_prof};
+             a.n_prof, a.rot, a.trans, a.world_x, a.world_y};
     // the scene's arc-length table once into LDS (the spline evaluations are done with it);
     // a table that never decreases -- every table of a sound reference line -- is bisected
     const int n_inv = a.n_inv[b];

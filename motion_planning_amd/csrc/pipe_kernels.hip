@@ -39,12 +39,21 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
                           int32_t dy_fstride, int32_t r_max, double *s_down, double *s_up, int32_t *n_reg,
                           int32_t *status, void *stream, const int32_t *key_n_s, int32_t *key_out);
 
+int mp_scene_ingest_into(int32_t B, const double *rot, const double *trans, const double *ego_vel_w,
+                         const double *way_xy, const int32_t *n_way, int32_t way_max, const double *ob_pos,
+                         const double *ob_vel, const double *ob_rad, const int32_t *n_ob, int32_t ob_max,
+                         double ignore_dist, int32_t n_frames, double dt, double *knots_x, double *knots_y,
+                         double *ego_vel_r, double *st_pos, double *st_rad, int32_t *n_st, int32_t st_max,
+                         double *dy_pos, double *dy_rad, int32_t *n_dy, int32_t dy_max, int32_t *overflow,
+                         void *stream);
+
 // ---------------------------------------------------------------------------
 // Arena layout: X(name, C type, MP_F64 / MP_I32, dim0, dim1, dim2, dim3)
 // ---------------------------------------------------------------------------
 #define NOB(d) ((d).n_st_max + (d).n_dy_max * (d).n_frames > 0 ? (d).n_st_max + (d).n_dy_max * (d).n_frames : 1)
 #define ONE(n) ((n) > 0 ? (n) : 1)
 #define OPT(d, n) ((d).want_maps ? (n) : 0)
+#define WLD(d, n) ((d).world ? (n) : 0) // arrays of the world-frame call only
 // The first PLAN_N_ZEROED arrays are cleared by one memset at the start of every call
 // (result rows whose unused tails no kernel writes, and the zero inputs).
 #define PLAN_N_ZEROED 13
@@ -112,7 +121,19 @@ int mp_st_regions_strided(int32_t B, int32_t n_t, const double *path_s, const do
     X(final_status, int32_t, MP_I32, d.B, 1, 1, 1)                                           \
     X(final_x, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
     X(final_y, double, MP_F64, d.B, d.q_max, 1, 1)                                           \
-    X(order_ws, int32_t, MP_I32, d.B, 2, 1, 1)
+    X(order_ws, int32_t, MP_I32, d.B, 2, 1, 1)                                               \
+    X(w_knots_x, double, MP_F64, WLD(d, d.B), d.n_knots_max, 1, 1)                           \
+    X(w_knots_y, double, MP_F64, WLD(d, d.B), d.n_knots_max, 1, 1)                           \
+    X(w_ego_vel, double, MP_F64, WLD(d, d.B), 2, 1, 1)                                       \
+    X(w_st_pos, double, MP_F64, WLD(d, d.B), ONE(d.n_st_max), 2, 1)                          \
+    X(w_st_rad, double, MP_F64, WLD(d, d.B), ONE(d.n_st_max), 1, 1)                          \
+    X(w_n_st, int32_t, MP_I32, WLD(d, d.B), 1, 1, 1)                                         \
+    X(w_dy_pos, double, MP_F64, WLD(d, d.B), ONE(d.n_dy_max), d.n_frames, 2)                 \
+    X(w_dy_rad, double, MP_F64, WLD(d, d.B), ONE(d.n_dy_max), 1, 1)                          \
+    X(w_n_dy, int32_t, MP_I32, WLD(d, d.B), 1, 1, 1)                                         \
+    X(w_status, int32_t, MP_I32, WLD(d, d.B), 1, 1, 1)                                       \
+    X(world_x, double, MP_F64, WLD(d, d.B), d.q_max, 1, 1)                                   \
+    X(world_y, double, MP_F64, WLD(d, d.B), d.q_max, 1, 1)
 
 struct PlanPtrs {
 #define X(name, ctype, dt, d0, d1, d2, d3) ctype *name;
@@ -257,9 +278,12 @@ __global__ void plan_frontend_kernel(FrontDev a)
     const int M = a.o.tab_m[b];
     const bool line_ok = a.o.rl_status[b] == MP_RL_OK && M > 0;
     const double end_s = a.o.origin[4 * b + 2];
-    if (!line_ok || end_s > a.max_map_len) {
+    // (world-frame call: a scene that kept more obstacles than its slots hold is not planned)
+    const bool crowded = a.o.w_status && a.o.w_status[b] != 0;
+    if (!line_ok || end_s > a.max_map_len || crowded) {
         if (tid == 0) {
-            a.o.status[b] = line_ok ? MP_PLAN_E_MAP_TOO_BIG : MP_PLAN_E_BAD_LINE;
+            a.o.status[b] = !line_ok ? MP_PLAN_E_BAD_LINE
+                                     : (end_s > a.max_map_len ? MP_PLAN_E_MAP_TOO_BIG : MP_PLAN_E_CAPACITY);
             a.o.n_layers[b] = 0;
             a.o.n_ob[b] = 0;
             a.o.order_ws[b] = 0;
@@ -325,15 +349,33 @@ __global__ void plan_frontend_kernel(FrontDev a)
         a.o.status[b] = full ? MP_PLAN_E_CAPACITY : MP_PLAN_OK;
     }
 
+    // slots no obstacle uses read 0 in the Frenet arrays
+    for (int p = tid; p < n_slot; p += nt) {
+        const bool is_st = p < d.n_st_max;
+        const int o = is_st ? p : (p - d.n_st_max) / F;
+        if (is_st ? o < n_st : o < n_dy) continue;
+        if (is_st) {
+            a.o.st_s[(size_t)b * ONE(d.n_st_max) + o] = 0.0;
+            a.o.st_l[(size_t)b * ONE(d.n_st_max) + o] = 0.0;
+        } else {
+            const size_t q = (size_t)b * ONE(d.n_dy_max) * F + (p - d.n_st_max);
+            a.o.dy_s[q] = 0.0;
+            a.o.dy_l[q] = 0.0;
+        }
+    }
+    // the scene's own obstacle frames, statics first (the slots in use are the first n_st of
+    // the statics' and the first n_dy * F of the dynamics')
+    const int n_used = n_st + n_dy * F;
     double r_loc = 0.0;
-    for (int p0 = 0; p0 < n_slot; p0 += nt) {
-        const int p = p0 + tid;
+    for (int p0 = 0; p0 < n_used; p0 += nt) {
+        const int pu = p0 + tid;
+        const int p = pu < n_st ? pu : d.n_st_max + (pu - n_st);
         bool keep = false;
         double s = 0.0, l = 0.0;
-        if (p < n_slot) {
+        if (pu < n_used) {
             const bool is_st = p < d.n_st_max;
             const int o = is_st ? p : (p - d.n_st_max) / F;
-            const bool used = is_st ? o < n_st : o < n_dy;
+            const bool used = true;
             double rad = 0.0;
             if (used) {
                 double x, y;
@@ -407,7 +449,7 @@ static int pipe_launch_check(const char *what)
 
 static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                             void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out,
-                            hipEvent_t *stage_ev = nullptr);
+                            hipEvent_t *stage_ev = nullptr, const mp_world_batch *world = nullptr);
 
 extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                               void *arena, int64_t arena_bytes, void *stream)
@@ -415,20 +457,45 @@ extern "C" int mp_plan_scenes(const mp_scene_batch *scenes, const mp_plan_dims *
     return plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr);
 }
 
+extern "C" int mp_plan_world_scenes(const mp_world_batch *world, const mp_plan_dims *dims,
+                                    const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream)
+{
+    if (!world) { mp_set_error("mp_plan_world_scenes: null scenes"); return MP_E_BADARG; }
+    return plan_scenes_impl(nullptr, dims, params, arena, arena_bytes, stream, nullptr, nullptr, world);
+}
+
 // stage_ev: null, or MP_PLAN_N_STAGES + 1 events; event 0 is recorded before the first
 // stage and event i + 1 behind stage i (mp_plan_scenes_timed).
+// world: null (robot-frame scenes in *scenes), or world-frame scenes: the ingestion stage then
+// writes the robot-frame scene into the arena and the chain runs on that.
 static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *dims, const mp_plan_params *params,
                             void *arena, int64_t arena_bytes, void *stream, PlanPtrs *ptrs_out,
-                            hipEvent_t *stage_ev)
+                            hipEvent_t *stage_ev, const mp_world_batch *world)
 {
     int rc = check_dims(dims);
     if (rc) return rc;
-    if (!scenes || !params || !arena) { mp_set_error("null scenes/params/arena"); return MP_E_BADARG; }
+    if ((!scenes && !world) || !params || !arena) { mp_set_error("null scenes/params/arena"); return MP_E_BADARG; }
     const mp_plan_dims d = *dims;
-    const mp_scene_batch &in = *scenes;
-    if (!in.knots_x || !in.knots_y || !in.n_knots || !in.line_vec || !in.ego_vel ||
+    if (world) {
+        const mp_world_batch &w = *world;
+        if (!d.world) { mp_set_error("mp_plan_world_scenes: dims.world must be 1 (the arena holds the scene)"); return MP_E_BADARG; }
+        if (w.ob_max < 0 || !(w.frame_dt > 0)) { mp_set_error("mp_world_batch: bad ob_max / frame_dt"); return MP_E_BADARG; }
+        if (!w.rot || !w.trans || !w.ego_vel_w || !w.way_xy || !w.n_way || !w.n_ob ||
+            (w.ob_max > 0 && (!w.ob_pos || !w.ob_vel || !w.ob_rad))) {
+            mp_set_error("mp_world_batch: null array");
+            return MP_E_BADARG;
+        }
+        if (w.ob_max > 0 && (d.n_st_max <= 0 || d.n_dy_max <= 0)) {
+            mp_set_error("mp_plan_world_scenes: n_st_max and n_dy_max must be positive when scenes hold obstacles");
+            return MP_E_BADARG;
+        }
+    }
+    mp_scene_batch in;
+    if (scenes) in = *scenes;
+    else memset(&in, 0, sizeof(in));
+    if (!world && (!in.knots_x || !in.knots_y || !in.n_knots || !in.line_vec || !in.ego_vel ||
         (d.n_st_max > 0 && (!in.st_pos || !in.st_rad || !in.n_st)) ||
-        (d.n_dy_max > 0 && (!in.dy_pos || !in.dy_rad || !in.n_dy))) {
+        (d.n_dy_max > 0 && (!in.dy_pos || !in.dy_rad || !in.n_dy)))) {
         mp_set_error("mp_scene_batch: null array");
         return MP_E_BADARG;
     }
@@ -479,6 +546,30 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
     if (hipMemsetAsync(arena, 0, (size_t)tab[PLAN_N_ZEROED].offset, st) != hipSuccess) {
         mp_set_error("mp_plan_scenes: memset failed");
         return MP_E_LAUNCH;
+    }
+    PLAN_STAGE_DONE();
+
+    // 0. world-frame scenes: into the robot frame, obstacles classified and filtered, the
+    //    moving ones' frames rolled out (coor_trans); the chain then reads the arena's scene
+    if (world) {
+        const mp_world_batch &w = *world;
+        rc = mp_scene_ingest_into(B, w.rot, w.trans, w.ego_vel_w, w.way_xy, w.n_way, d.n_knots_max, w.ob_pos,
+                                  w.ob_vel, w.ob_rad, w.n_ob, w.ob_max, w.ignore_dist, d.n_frames, w.frame_dt,
+                                  o.w_knots_x, o.w_knots_y, o.w_ego_vel, o.w_st_pos, o.w_st_rad, o.w_n_st,
+                                  ONE(d.n_st_max), o.w_dy_pos, o.w_dy_rad, o.w_n_dy, ONE(d.n_dy_max), o.w_status,
+                                  stream);
+        if (rc) return rc;
+        in.knots_x = o.w_knots_x;
+        in.knots_y = o.w_knots_y;
+        in.n_knots = w.n_way;
+        in.line_vec = w.line_vec ? w.line_vec : o.zeros; // zeros: B x 2 cleared doubles
+        in.ego_vel = o.w_ego_vel;
+        in.st_pos = o.w_st_pos;
+        in.st_rad = o.w_st_rad;
+        in.n_st = o.w_n_st;
+        in.dy_pos = o.w_dy_pos;
+        in.dy_rad = o.w_dy_rad;
+        in.n_dy = o.w_n_dy;
     }
     PLAN_STAGE_DONE();
 
@@ -584,6 +675,10 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
         a.final_s = o.final_s; a.final_l = o.final_l; a.n_final = o.n_final; a.final_status = o.final_status;
         a.inv_x = o.inv_x; a.inv_s = o.inv_s; a.inv_y = o.inv_y; a.inv_theta = o.inv_theta; a.n_inv = o.n_inv;
         a.final_x = o.final_x; a.final_y = o.final_y;
+        a.rot = world ? world->rot : nullptr;
+        a.trans = world ? world->trans : nullptr;
+        a.world_x = world ? o.world_x : nullptr;
+        a.world_y = world ? o.world_y : nullptr;
         rc = mp_plan_tail_stage(B, a, stream);
         if (rc) return rc;
     }
@@ -597,7 +692,8 @@ static int plan_scenes_impl(const mp_scene_batch *scenes, const mp_plan_dims *di
 }
 
 static const char *const g_stage_names[MP_PLAN_N_STAGES] = {
-    "clear result rows (memset)", "reference-line tables", "front end (Frenet map, obstacle list)",
+    "clear result rows (memset)", "scene ingestion (world to robot frame; world-frame scenes only)",
+    "reference-line tables", "front end (Frenet map, obstacle list)",
     "SL path DP", "path spline (knots, samples, ST grid width)", "ST blocked intervals", "ST speed DP",
     "speed profile, path points, Frenet to Cartesian"};
 
@@ -606,9 +702,28 @@ extern "C" const char *mp_plan_stage_name(int32_t i)
     return (i >= 0 && i < MP_PLAN_N_STAGES) ? g_stage_names[i] : nullptr;
 }
 
+static int plan_scenes_timed_impl(const mp_scene_batch *scenes, const mp_world_batch *world, const mp_plan_dims *dims,
+                                  const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream,
+                                  float *stage_ms);
+
 extern "C" int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_dims *dims,
                                     const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream,
                                     float *stage_ms)
+{
+    return plan_scenes_timed_impl(scenes, nullptr, dims, params, arena, arena_bytes, stream, stage_ms);
+}
+
+extern "C" int mp_plan_world_scenes_timed(const mp_world_batch *world, const mp_plan_dims *dims,
+                                          const mp_plan_params *params, void *arena, int64_t arena_bytes,
+                                          void *stream, float *stage_ms)
+{
+    if (!world) { mp_set_error("mp_plan_world_scenes_timed: null scenes"); return MP_E_BADARG; }
+    return plan_scenes_timed_impl(nullptr, world, dims, params, arena, arena_bytes, stream, stage_ms);
+}
+
+static int plan_scenes_timed_impl(const mp_scene_batch *scenes, const mp_world_batch *world, const mp_plan_dims *dims,
+                                  const mp_plan_params *params, void *arena, int64_t arena_bytes, void *stream,
+                                  float *stage_ms)
 {
     if (!stage_ms) { mp_set_error("mp_plan_scenes_timed: null stage_ms"); return MP_E_BADARG; }
     hipEvent_t ev[MP_PLAN_N_STAGES + 1];
@@ -616,7 +731,7 @@ extern "C" int mp_plan_scenes_timed(const mp_scene_batch *scenes, const mp_plan_
     int rc = MP_OK;
     for (; made <= MP_PLAN_N_STAGES; ++made)
         if (hipEventCreate(&ev[made]) != hipSuccess) { mp_set_error("hipEventCreate failed"); rc = MP_E_LAUNCH; break; }
-    if (!rc) rc = plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr, ev);
+    if (!rc) rc = plan_scenes_impl(scenes, dims, params, arena, arena_bytes, stream, nullptr, ev, world);
     if (!rc && hipEventSynchronize(ev[MP_PLAN_N_STAGES]) != hipSuccess) {
         mp_set_error("mp_plan_scenes_timed: hipEventSynchronize failed");
         rc = MP_E_LAUNCH;

@@ -26,7 +26,8 @@ struct PlanPathDev {
 // s = index * ds (speed_planner.py:35-46); the speed profile every dt/5 (speed_planner.py:22,47);
 // the path spline at the profile's arc lengths (path_sampling(curve, False, ss),
 // planner_interface.py:157); those points in the robot frame
-// (cartesian_frenet_conversion.py:55-60); and the scene's final status.
+// (cartesian_frenet_conversion.py:55-60) and, for world-frame scenes, in the world frame
+// (robot_map.py:84-91); and the scene's final status.
 struct PlanTailDev {
     int32_t n_t, n_pk_max, q_max, m_max;
     double st_ds, st_dt, curve_dt, path_dt;
@@ -45,6 +46,9 @@ struct PlanTailDev {
     const double *inv_x, *inv_s, *inv_y, *inv_theta;
     const int32_t *n_inv;
     double *final_x, *final_y;
+    // from world-frame scenes only (null otherwise): ego poses and the path in the world frame
+    const double *rot, *trans;
+    double *world_x, *world_y;
 };
 
 int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream);

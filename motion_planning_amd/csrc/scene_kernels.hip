@@ -16,6 +16,8 @@
 
 struct SceneDev {
     int32_t way_max, ob_max, n_frames;
+    int32_t st_max, dy_max; // slots per scene of the kept statics / dynamics (mp_scene_ingest: ob_max each)
+    int32_t *overflow;      // null, or per scene 1 when more obstacles were kept than the slots hold, else 0
     const double *rot, *trans, *ego_vel_w;
     const double *way_xy;
     const int32_t *n_way;
@@ -94,13 +96,14 @@ __global__ void scene_ingest_kernel(SceneDev a)
         }
         const unsigned long long m_st = __ballot(cls == MP_OB_STATIC), m_dy = __ballot(cls == MP_OB_DYNAMIC);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (cls == MP_OB_STATIC) {
-            const size_t slot = ob0 + n_st + __popcll(m_st & below);
+        const int k_st = n_st + __popcll(m_st & below), k_dy = n_dy + __popcll(m_dy & below);
+        if (cls == MP_OB_STATIC && k_st < a.st_max) {
+            const size_t slot = (size_t)b * a.st_max + k_st;
             a.st_pos[slot * 2] = px;
             a.st_pos[slot * 2 + 1] = py;
             a.st_rad[slot] = a.ob_rad[ob0 + o];
-        } else if (cls == MP_OB_DYNAMIC) {
-            const size_t slot = ob0 + n_dy + __popcll(m_dy & below);
+        } else if (cls == MP_OB_DYNAMIC && k_dy < a.dy_max) {
+            const size_t slot = (size_t)b * a.dy_max + k_dy;
             double qx = px, qy = py;
             double *out = a.dy_pos + slot * a.n_frames * 2;
             for (int k = 0; k < a.n_frames; ++k) {
@@ -119,8 +122,9 @@ __global__ void scene_ingest_kernel(SceneDev a)
         n_dy += __popcll(m_dy);
     }
     if (lane == 0) {
-        a.n_st[b] = n_st;
-        a.n_dy[b] = n_dy;
+        a.n_st[b] = min(n_st, a.st_max);
+        a.n_dy[b] = min(n_dy, a.dy_max);
+        if (a.overflow) a.overflow[b] = (n_st > a.st_max || n_dy > a.dy_max) ? 1 : 0;
     }
 }
 
@@ -167,11 +171,29 @@ extern "C" int mp_scene_ingest(int32_t B, const double *rot, const double *trans
         mp_set_error("mp_scene_ingest: null array");
         return MP_E_BADARG;
     }
-    SceneDev a{way_max, ob_max, n_frames, rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob,
-               ignore_dist, dt, knots_x, knots_y, ego_vel_r, st_pos, st_rad, n_st, dy_pos, dy_vel, dy_rad, n_dy,
-               ob_class};
+    SceneDev a{way_max, ob_max, n_frames, ob_max, ob_max, nullptr, rot, trans, ego_vel_w, way_xy, n_way, ob_pos,
+               ob_vel, ob_rad, n_ob, ignore_dist, dt, knots_x, knots_y, ego_vel_r, st_pos, st_rad, n_st, dy_pos,
+               dy_vel, dy_rad, n_dy, ob_class};
     hipLaunchKernelGGL(scene_ingest_kernel, dim3(B), dim3(MP_WAVE), 0, (hipStream_t)stream, a);
     return scene_launch_check("mp_scene_ingest");
+}
+
+// The same kernel for the whole replan from world-frame scenes: kept statics / dynamics go
+// into rows of st_max / dy_max slots (fewer than ob_max where the caller knows a bound), and
+// overflow[b] tells whether scene b kept more than fit.  Arguments were checked by the chain.
+int mp_scene_ingest_into(int32_t B, const double *rot, const double *trans, const double *ego_vel_w,
+                         const double *way_xy, const int32_t *n_way, int32_t way_max, const double *ob_pos,
+                         const double *ob_vel, const double *ob_rad, const int32_t *n_ob, int32_t ob_max,
+                         double ignore_dist, int32_t n_frames, double dt, double *knots_x, double *knots_y,
+                         double *ego_vel_r, double *st_pos, double *st_rad, int32_t *n_st, int32_t st_max,
+                         double *dy_pos, double *dy_rad, int32_t *n_dy, int32_t dy_max, int32_t *overflow,
+                         void *stream)
+{
+    SceneDev a{way_max, ob_max, n_frames, st_max, dy_max, overflow, rot, trans, ego_vel_w, way_xy, n_way, ob_pos,
+               ob_vel, ob_rad, n_ob, ignore_dist, dt, knots_x, knots_y, ego_vel_r, st_pos, st_rad, n_st, dy_pos,
+               nullptr, dy_rad, n_dy, nullptr};
+    hipLaunchKernelGGL(scene_ingest_kernel, dim3(B), dim3(MP_WAVE), 0, (hipStream_t)stream, a);
+    return scene_launch_check("mp_plan_world_scenes (scene ingestion)");
 }
 
 extern "C" int mp_robot_to_world(int32_t n_pts, const double *x, const double *y, const int32_t *pt_scn,

@@ -42,8 +42,12 @@ def pack_results(path_idx, status, layers_done, best_cost, st_path, st_len, out=
         # the kernel reads int32 / float64 through raw pointers
         args = [t.to(torch.float64 if t is best_cost else torch.int32).contiguous()
                 for t in (path_idx, status, layers_done, best_cost, st_path, st_len)]
-        if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.shape == (B, width)):
-            raise ValueError("pack_results: out must be a contiguous CUDA uint8 tensor [%d, %d]" % (B, width))
+        # (pinned host memory is mapped into the device's address space: the kernel can
+        # store the records straight into it, which saves a separate device-to-host copy)
+        if not ((out.is_cuda or out.is_pinned()) and out.dtype == torch.uint8 and out.is_contiguous()
+                and out.shape == (B, width)):
+            raise ValueError("pack_results: out must be a contiguous uint8 tensor [%d, %d] in device or pinned host "
+                             "memory" % (B, width))
         _lib.check(_lib.lib().mp_pack_results(B, n_s, n_t, *[_p(t) for t in args], _p(out), _stream()),
                    "mp_pack_results")
         return out

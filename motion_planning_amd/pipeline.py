@@ -25,6 +25,7 @@ PIPE_OK, PIPE_NOT_FOUND = _lib.MP_PLAN_OK, _lib.MP_PLAN_NOT_FOUND
 PIPE_MAP_TOO_BIG, PIPE_BAD_LINE, PIPE_ST_CAPACITY = (_lib.MP_PLAN_E_MAP_TOO_BIG, _lib.MP_PLAN_E_BAD_LINE,
                                                     _lib.MP_PLAN_E_ST_CAPACITY)
 PIPE_INDEX = _lib.MP_PLAN_E_INDEX  # the reference raises IndexError while sampling the result
+PIPE_CAPACITY = _lib.MP_PLAN_E_CAPACITY
 N_FRAMES = 11  # dynamic-obstacle frames: t = 0, 0.5, ..., 5.0 (Model/obstacle.py:46-53)
 
 
@@ -93,9 +94,10 @@ class PlanArena:
 
 
 def plan_dims(B, n_knots_max, n_st_max, n_dy_max, n_l=5, m_max=232, plan_time=5, params=None, want_maps=False,
-              n_frames=N_FRAMES, r_max=None):
+              n_frames=N_FRAMES, r_max=None, world=False):
     """Arena sizes for scenes of the given shape: capacities follow from the map length
-    limit (100 m) and the sampling constants."""
+    limit (100 m) and the sampling constants.  world: the arena also holds the ingested
+    scene and the world-frame path (plan_world_scenes)."""
     p = params or default_params()
     n_t = int(math.ceil(1.0 * plan_time / p.st_dt)) + 1            # st_map.py:18
     n_s_max = int(p.max_map_len / p.layer_gap) + 2
@@ -105,7 +107,7 @@ def plan_dims(B, n_knots_max, n_st_max, n_dy_max, n_l=5, m_max=232, plan_time=5,
     if r_max is None:
         r_max = max(1, min(n_st_max + n_dy_max, 256))
     return PlanDims(B, n_knots_max, n_st_max, n_dy_max, n_frames, n_l, m_max, n_s_max, p_max, n_t, st_n_s_max,
-                    r_max, q_max, int(bool(want_maps)))
+                    r_max, q_max, int(bool(want_maps)), int(bool(world)))
 
 
 def plan_scenes(scenes, dims, params, arena=None):
@@ -126,6 +128,37 @@ def plan_scenes_timed(scenes, dims, params, arena=None):
     ms = (C.c_float * _lib.MP_PLAN_N_STAGES)()
     check(lib().mp_plan_scenes_timed(C.byref(sb), C.byref(dims), C.byref(params), C.c_void_p(arena.base.data_ptr()),
                                      arena.nbytes, mb._stream(), ms), "mp_plan_scenes_timed")
+    return arena, [(lib().mp_plan_stage_name(i).decode(), float(ms[i])) for i in range(_lib.MP_PLAN_N_STAGES)]
+
+
+def _world_batch(world, ignore_dist, frame_dt):
+    """mp_world_batch from a dict of device tensors named as its pointer fields."""
+    ob_max = int(world["ob_rad"].shape[1]) if world.get("ob_rad") is not None and world["ob_rad"].dim() == 2 else 0
+    ptrs = [mb._p(world.get(n)) for n, t in _lib.WorldBatch._fields_ if t is _lib._vp]
+    return _lib.WorldBatch(*ptrs, ob_max, 0, float(ignore_dist), float(frame_dt))
+
+
+def plan_world_scenes(world, dims, params, arena=None, ignore_dist=20.0, frame_dt=0.5):
+    """Enqueues one mp_plan_world_scenes call: world-frame scenes in, world-frame paths out
+    (PlannerInterface.run_step, planner_interface.py:35-95, for B scenes).  world: dict of
+    device tensors rot [B, 4], trans [B, 2], ego_vel_w [B, 2], way_xy [B, W, 2], n_way [B],
+    ob_pos / ob_vel [B, O, 2], ob_rad [B, O], n_ob [B] and optionally line_vec [B].  dims
+    must have been made with world=True.  Returns the arena."""
+    arena = arena or PlanArena(dims)
+    wb = _world_batch(world, ignore_dist, frame_dt)
+    check(lib().mp_plan_world_scenes(C.byref(wb), C.byref(dims), C.byref(params), C.c_void_p(arena.base.data_ptr()),
+                                     arena.nbytes, mb._stream()), "mp_plan_world_scenes")
+    return arena
+
+
+def plan_world_scenes_timed(world, dims, params, arena=None, ignore_dist=20.0, frame_dt=0.5):
+    """plan_world_scenes with a HIP event between its stages (measurement aid; blocks)."""
+    arena = arena or PlanArena(dims)
+    wb = _world_batch(world, ignore_dist, frame_dt)
+    ms = (C.c_float * _lib.MP_PLAN_N_STAGES)()
+    check(lib().mp_plan_world_scenes_timed(C.byref(wb), C.byref(dims), C.byref(params),
+                                           C.c_void_p(arena.base.data_ptr()), arena.nbytes, mb._stream(), ms),
+          "mp_plan_world_scenes_timed")
     return arena, [(lib().mp_plan_stage_name(i).decode(), float(ms[i])) for i in range(_lib.MP_PLAN_N_STAGES)]
 
 
@@ -222,22 +255,60 @@ def _tables_view(arr, B, m_max):
 
 
 def plan_world_batch(rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob, ignore_dist=20.0,
-                     **plan_args):
-    """World-frame scenes end to end: what PlannerInterface.run_step computes between
-    coor_trans and the two path_convert calls (planner_interface.py:54-68) for B scenes.
+                     line_vec=None, l_width=3.5, save_width=0.6, n_l=5, speed_lim=25.0 * 5.0 / 18.0, plan_time=5,
+                     want_maps=False, path_planner="dp", m_max=None, arena=None, n_st_max=None, n_dy_max=None):
+    """World-frame scenes end to end in ONE library call (mp_plan_world_scenes): what
+    PlannerInterface.run_step computes from coor_trans to the two path_convert calls
+    (planner_interface.py:35-95) for B scenes.
 
     rot [B, 2, 2] ego rotation, trans [B, 2] ego position, ego_vel_w [B, 2]; way_xy
     [B, W, 2] lane waypoints ahead, n_way [B]; obstacles ob_pos / ob_vel [B, O, 2],
-    ob_rad [B, O], n_ob [B], all in the world frame.  Returns plan_batch's dict plus
-    `scene` (the ingested robot-frame scene) and `world_x` / `world_y` [B, q_max], the
-    final path of every scene in the world frame (n_prof[b] valid points)."""
-    sc = mb.scene_ingest(rot, trans, ego_vel_w, way_xy, n_way, ob_pos, ob_vel, ob_rad, n_ob, ignore_dist)
-    res = plan_batch(sc["knots_x"], sc["knots_y"], n_way, sc["ego_vel"], sc["st_pos"], sc["st_rad"], sc["n_st"],
-                     sc["dy_pos"], sc["dy_rad"], sc["n_dy"], **plan_args)
-    res["scene"] = sc
-    B, q_max = res["final_x"].shape
-    scn = torch.arange(B, dtype=torch.int32, device=res["final_x"].device).repeat_interleave(q_max)
-    wx, wy = mb.robot_to_world(mb.to_dev(rot).reshape(-1, 4), mb.to_dev(trans).reshape(-1, 2), res["final_x"],
-                               res["final_y"], scn)
-    res.update(world_x=wx.view(B, q_max), world_y=wy.view(B, q_max))
+    ob_rad [B, O], n_ob [B], all in the world frame.  n_st_max / n_dy_max: slots for the
+    kept static / moving obstacles of a scene (default O each; a scene that keeps more
+    reports PIPE_CAPACITY).  Returns plan_batch's dict plus `scene` (the ingested
+    robot-frame scene, views into the arena) and `world_x` / `world_y` [B, q_max], the final
+    path of every scene in the world frame (n_final[b] valid points, 0 behind them)."""
+    if path_planner not in ("dp", "track"):
+        raise ValueError("path_planner must be 'dp' or 'track'")
+    rot, trans = mb.to_dev(rot).reshape(-1, 4).contiguous(), mb.to_dev(trans).reshape(-1, 2).contiguous()
+    B = rot.shape[0]
+    ego_vel_w = mb.to_dev(ego_vel_w).reshape(B, 2).contiguous()
+    way_xy = mb.to_dev(way_xy).reshape(B, -1, 2).contiguous()
+    W = way_xy.shape[1]
+    n_way, n_ob = mb.to_dev(n_way, torch.int32), mb.to_dev(n_ob, torch.int32)
+    def rows(x, *tail):
+        x = mb.to_dev(x)
+        return x.reshape((B, -1) + tail).contiguous() if x.numel() else x.new_zeros((B, 0) + tail)
+
+    ob_pos, ob_vel, ob_rad = rows(ob_pos, 2), rows(ob_vel, 2), rows(ob_rad)
+    O = ob_pos.shape[1]
+    assert ob_vel.shape[1] == O and ob_rad.shape[1] == O
+    if m_max is None:
+        # samples of the reference line: from the waypoints' abscissae in the robot frame,
+        # R^T (p - t) (one device->host read)
+        d = way_xy - trans[:, None, :]
+        kx = rot[:, 0:1] * d[:, :, 0] + rot[:, 2:3] * d[:, :, 1]
+        used = torch.arange(W, device=kx.device)[None, :] < n_way[:, None]
+        big = torch.finfo(kx.dtype).max
+        span = (torch.where(used, kx, -big).max(dim=1).values - torch.where(used, kx, big).min(dim=1).values)
+        m_max = int(float(span.clamp(min=0).max()) / 0.5) + 8 if kx.numel() else 8
+    world = dict(rot=rot, trans=trans, ego_vel_w=ego_vel_w, way_xy=way_xy, n_way=n_way, n_ob=n_ob,
+                 line_vec=None if line_vec is None else mb.to_dev(line_vec))
+    if O:
+        world.update(ob_pos=ob_pos, ob_vel=ob_vel, ob_rad=ob_rad)
+    Ns = O if n_st_max is None else int(n_st_max)
+    Nd = O if n_dy_max is None else int(n_dy_max)
+    params = default_params(l_width=l_width, save_width=save_width, speed_lim=speed_lim,
+                            path_planner=0 if path_planner == "dp" else 1)
+    dims = plan_dims(B, W, Ns, Nd, n_l=n_l, m_max=m_max, plan_time=plan_time, params=params, want_maps=want_maps,
+                     world=True)
+    if arena is not None and bytes(arena.dims) != bytes(dims):
+        raise ValueError("arena was laid out for other sizes")
+    arena = plan_world_scenes(world, dims, params, arena, ignore_dist=ignore_dist)
+    res = dict(arena.arrays)
+    scene = dict(knots_x=res["w_knots_x"], knots_y=res["w_knots_y"], ego_vel=res["w_ego_vel"], st_pos=res["w_st_pos"],
+                 st_rad=res["w_st_rad"], n_st=res["w_n_st"], dy_pos=res["w_dy_pos"], dy_rad=res["w_dy_rad"],
+                 n_dy=res["w_n_dy"])
+    res.update(arena=arena, dims=dims, world=world, scene=scene, scenes=scene, n_s=res["n_layers"],
+               tables=_tables_view(res, B, m_max))
     return res

@@ -235,3 +235,103 @@ def test_pack_results_device_matches_host():
     assert torch.equal(u["layers_done"].cpu(), layers) and torch.equal(u["st_path"].cpu(), st_path)
     assert torch.equal(u["st_len"].cpu(), st_len)
     assert torch.equal(u["best_cost"].cpu().view(torch.int64), best.view(torch.int64))
+
+
+def random_world_scenes(rng, B, W, O):
+    theta = rng.uniform(-math.pi, math.pi, B)
+    rot = np.array([[[math.cos(t), -math.sin(t)], [math.sin(t), math.cos(t)]] for t in theta])
+    trans = rng.uniform(-300, 300, (B, 2))
+    ego_vel_r = np.stack([rng.uniform(3, 8, B), rng.uniform(-0.5, 0.5, B)], 1)
+    n_way = rng.integers(7, W + 1, B).astype(np.int32)
+    c = rng.uniform(-0.006, 0.006, B)
+    way_r = np.zeros((B, W, 2))
+    for b in range(B):
+        xs = -2.0 + 4.5 * np.arange(n_way[b])
+        way_r[b, :n_way[b], 0], way_r[b, :n_way[b], 1] = xs, c[b] * xs * xs
+    n_ob = rng.integers(0, O + 1, B).astype(np.int32)
+    n_ob[0], n_ob[1] = O, 0
+    ob_r = np.stack([rng.uniform(-6, 70, (B, O)), rng.uniform(-9, 9, (B, O))], 2)
+    ob_vel_r = np.stack([rng.uniform(-3, 3, (B, O)), rng.uniform(-0.3, 0.3, (B, O))], 2)
+    ob_vel_r[rng.random((B, O)) < 0.6] = 0.0
+
+    def to_world(p):
+        return np.einsum("bij,b...j->b...i", rot, p) + trans.reshape((B,) + (1,) * (p.ndim - 2) + (2,))
+
+    return dict(rot=rot, trans=trans, ego_vel_w=np.einsum("bij,bj->bi", rot, ego_vel_r), way_xy=to_world(way_r),
+                n_way=n_way, ob_pos=to_world(ob_r), ob_vel=np.einsum("bij,boj->boi", rot, ob_vel_r),
+                ob_rad=rng.uniform(0.4, 1.0, (B, O)), n_ob=n_ob)
+
+
+@pytest.mark.parametrize("planner", ["dp", "track"])
+def test_world_scenes_in_one_call_equal_the_three_calls(planner):
+    """mp_plan_world_scenes (ingestion, the replan chain and the way back to the world frame in
+    one enqueue, nothing but kernels in between) against the same three steps as separate
+    library calls: mp_scene_ingest, mp_plan_scenes, mp_robot_to_world.  Bit for bit."""
+    import torch
+    from motion_planning_amd import batch as mb, pipeline as pl
+    rng = np.random.default_rng(77)
+    B, W, O = 48, 21, 40
+    w = random_world_scenes(rng, B, W, O)
+    res = pl.plan_world_batch(w["rot"], w["trans"], w["ego_vel_w"], w["way_xy"], w["n_way"], w["ob_pos"], w["ob_vel"],
+                              w["ob_rad"], w["n_ob"], path_planner=planner, m_max=200)
+    sc = mb.scene_ingest(w["rot"], w["trans"], w["ego_vel_w"], w["way_xy"], w["n_way"], w["ob_pos"], w["ob_vel"],
+                         w["ob_rad"], w["n_ob"])
+    ref = pl.plan_batch(sc["knots_x"], sc["knots_y"], w["n_way"], sc["ego_vel"], sc["st_pos"], sc["st_rad"], sc["n_st"],
+                        sc["dy_pos"], sc["dy_rad"], sc["n_dy"], path_planner=planner, m_max=200)
+    q_max = ref["final_x"].shape[1]
+    scn = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(q_max)
+    wx, wy = mb.robot_to_world(w["rot"], w["trans"], ref["final_x"], ref["final_y"], scn)
+    torch.cuda.synchronize()
+    status = res["status"].cpu().numpy()
+    assert (status == 1).any() and set(np.unique(status)) <= {1, 0, -4}
+    for k in ("knots_x", "knots_y", "ego_vel", "n_st", "n_dy"):
+        assert torch.equal(res["scene"][k], sc[k]), k
+    n_st, n_dy = sc["n_st"].cpu().numpy(), sc["n_dy"].cpu().numpy()
+    for b in range(B):
+        for k, n in (("st_pos", n_st[b]), ("st_rad", n_st[b]), ("dy_pos", n_dy[b]), ("dy_rad", n_dy[b])):
+            assert torch.equal(res["scene"][k][b, :n], sc[k][b, :n]), (k, b)
+    for k in ("status", "n_final", "n_prof", "path_idx", "st_path_s_ind", "final_x", "final_y", "vv", "ss", "final_s",
+              "final_l", "ob_s", "ob_l", "n_ob", "s_layers", "n_layers", "st_n_s"):
+        a_, b_ = res[k], ref[k]
+        if k in ("ob_s", "ob_l"):      # rows beyond a scene's own obstacle entries are never written
+            n = ref["n_ob"].cpu().numpy()
+            assert all(torch.equal(a_[b, :n[b]], b_[b, :n[b]]) for b in range(B)), k
+            continue
+        assert torch.equal(a_, b_) or (a_.is_floating_point() and torch.equal(a_.nan_to_num(), b_.nan_to_num())), k
+    n_final = res["n_final"].cpu().numpy()
+    gx, gy = res["world_x"].cpu().numpy(), res["world_y"].cpu().numpy()
+    wx, wy = wx.view(B, q_max).cpu().numpy(), wy.view(B, q_max).cpu().numpy()
+    for b in range(B):
+        n = n_final[b] if status[b] == 1 else 0
+        assert np.array_equal(gx[b, :n], wx[b, :n]) and np.array_equal(gy[b, :n], wy[b, :n])
+        assert (gx[b, n:] == 0).all() and (gy[b, n:] == 0).all()
+
+
+def test_world_scenes_with_fewer_slots_than_kept_obstacles():
+    """n_st_max / n_dy_max bound the obstacles a scene may KEEP: scenes within the bound plan
+    exactly as with roomy slots, a scene beyond it reports PIPE_CAPACITY and no path."""
+    import torch
+    from motion_planning_amd import batch as mb, pipeline as pl
+    rng = np.random.default_rng(78)
+    B, W, O = 32, 21, 40
+    w = random_world_scenes(rng, B, W, O)
+    args = (w["rot"], w["trans"], w["ego_vel_w"], w["way_xy"], w["n_way"], w["ob_pos"], w["ob_vel"], w["ob_rad"],
+            w["n_ob"])
+    roomy = pl.plan_world_batch(*args, m_max=200)
+    n_st, n_dy = roomy["scene"]["n_st"].cpu().numpy(), roomy["scene"]["n_dy"].cpu().numpy()
+    cap_st, cap_dy = int(np.sort(n_st)[-4]), int(np.sort(n_dy)[-4])      # the three fullest scenes do not fit
+    tight = pl.plan_world_batch(*args, m_max=200, n_st_max=max(cap_st, 1), n_dy_max=max(cap_dy, 1))
+    torch.cuda.synchronize()
+    over = (n_st > max(cap_st, 1)) | (n_dy > max(cap_dy, 1))
+    assert over.any() and not over.all()
+    st_r, st_t = roomy["status"].cpu().numpy(), tight["status"].cpu().numpy()
+    # (a map longer than 100 m is reported as such whether or not the scene is also too crowded)
+    want_over = np.where(st_r[over] == pl.PIPE_MAP_TOO_BIG, pl.PIPE_MAP_TOO_BIG, pl.PIPE_CAPACITY)
+    assert np.array_equal(st_t[over], want_over) and (st_t[over] == pl.PIPE_CAPACITY).any()
+    assert np.array_equal(st_t[~over], st_r[~over])
+    assert (tight["n_final"].cpu().numpy()[over] == 0).all()
+    for k in ("n_final", "final_x", "final_y", "world_x", "world_y", "vv", "path_idx"):
+        a_, b_ = tight[k][torch.as_tensor(~over)], roomy[k][torch.as_tensor(~over)]
+        assert torch.equal(a_.nan_to_num() if a_.is_floating_point() else a_,
+                           b_.nan_to_num() if b_.is_floating_point() else b_), k
+    assert (tight["world_x"].cpu().numpy()[over] == 0).all()
