@@ -30,7 +30,8 @@
  * MP_ORDER=0 (the *_ordered entry points launch in the caller's order),
  * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n (workgroup size of
  * mp_st_dp / mp_refline_tables / the front end of mp_plan_scenes; honoured only
- * when a multiple of 64 within 64..1024).
+ * when a multiple of 64 within 64..1024), MP_ST_LANES=4|8 (lanes that share a
+ * cell in mp_st_dp's relaxation).
  */
 #ifndef MPLATTICE_H
 #define MPLATTICE_H

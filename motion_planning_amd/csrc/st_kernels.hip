@@ -146,8 +146,15 @@ struct StCellLds {
 // Lanes per cell of the split relaxation.  Pruning makes the walks short, so in a large
 // batch (throughput) the cost of a pass over the cells counts as much as the balance of the
 // lanes: grids of up to 128 cells give a cell 4 lanes (two passes of 64 cells instead of four
-// of 32 on a 97-cell grid), wider ones 8.  A small batch (latency) keeps 8 lanes from 49 cells on.
-static inline int st_lanes_per_cell(int B, int n_s_max) { return n_s_max <= (B > 512 ? 128 : 48) ? 4 : 8; }
+// of 32 on a 97-cell grid), wider ones 8.  A small batch (latency) always takes 8 lanes: a layer
+// is then one pass (measured, one plan per call, replayed graph: 29 / 61 / 101 cells take
+// 50 / 60 / 73 us with 8 lanes and a workgroup as wide as the grid needs, 56 / 78 / 96 us with 4).
+int mp_knob_st_lanes();
+static inline int st_lanes_per_cell(int B, int n_s_max)
+{
+    if (mp_knob_st_lanes() > 0) return mp_knob_st_lanes(); // development aid
+    return (B > 512 && n_s_max <= 128) ? 4 : 8;
+}
 
 struct StSh {
     double *ch_prev, *ch_cur, *fs, *acc, *jerk2, *jerk3, *down, *up;
@@ -983,6 +990,9 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // n_s_max: the history word holds 8*(pp-2p) and 8*(3pp-ppp-3p) as signed 16-bit halves and
     // fire distances are u16 values of 16*d, so 24*n_s_max must stay below 32768 whatever LDS holds
     static_assert(24 * 1024 < 32768, "history word / fire distance encoding");
+    // n_s_max: the history word holds 8*(pp-2p) and 8*(3pp-ppp-3p) as signed 16-bit halves and
+    // fire distances are u16 values of 16*d, so 24*n_s_max must stay below 32768 whatever LDS holds
+    static_assert(24 * 1024 < 32768, "history word / fire distance encoding");
     if (n_t > 64 || n_s_max > 1024 || r_max > 256) {
         mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 256");
         return MP_E_UNSUPPORTED;
@@ -995,8 +1005,8 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
-    // wide grid gets more lanes per layer
-    if (B <= 512 && n_s_max > 64) threads = 512;
+    // grid gets the lanes that make a layer one pass (8 per cell), up to 512
+    if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
     size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + st_tab_bytes(n_s_max, r_tab);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
