@@ -18,6 +18,7 @@ int mp_knob_rl_threads();
 int mp_knob_fe_threads();
 int mp_knob_st_generic();
 int mp_knob_order(); // 0: the *_ordered entry points launch in the caller's order
+int mp_knob_sl_rows(); // predecessor rows of the fused SL kernel's compact form (tests: small values force its second launch)
 #define MP_INF (__builtin_huge_val())
 
 // ---- wave-level reductions (64 lanes) ---------------------------------------

@@ -33,6 +33,7 @@
 #include "mp_device.h"
 
 #define SL_E_REG 6   // (sample, obstacle) pairs kept in registers on the fused path
+#define SL_ROWS_COMPACT 16 // predecessor rows of the fused kernel's compact form (MP_SL_ROWS overrides)
 #define SL_E_CAP 48  // LDS capacity of the compacted pair list
 
 struct SlDev {
@@ -48,7 +49,14 @@ struct SlDev {
     int32_t pair_cap;  // fused kernel: (sample, obstacle) pairs the LDS pair store holds per scenario
     unsigned long long *n_evaluated; // counting instance of the fused kernel only: edges priced, summed over the batch
     const int32_t *order;            // fused kernel: workgroup i plans scenario order[i] (null: scenario i)
+    int32_t idx_rows;                // fused kernel: predecessor rows its LDS holds (one per layer that walks)
+    int32_t retry_only;              // fused kernel: plan only the scenarios whose status is SL_RETRY
 };
+
+// Internal status of the fused kernel's compact form (never leaves the library): the plan was
+// found but more layers walked than the kernel had predecessor rows for, so the path could not
+// be traced back; the launcher's second launch (every row in LDS) plans the scenario again.
+#define SL_RETRY (-100)
 
 struct LayerGeom {
     int K;         // samples on every edge of the layer (negative: MP_SL_E_* code)
@@ -283,6 +291,7 @@ struct PairStore {
     unsigned short *offL;           // LDS: first pair of the layer in the store
     unsigned *recL;                 // LDS (may be null): (pairs << 16 | first pair) of a stored layer, ~0u otherwise
     double *h0, *ol, *ds2;          // LDS: the store, cap entries each
+    unsigned short *lay;            // LDS (may be null): the layer every stored pair belongs to
 
     __device__ __forceinline__ LayerGeom geo(int s) const
     {
@@ -416,6 +425,7 @@ struct PairStore {
                 h0[slot] = basis_h0(x, T);
                 ol[slot] = ol_;
                 ds2[slot] = d2;
+                if (lay) lay[slot] = (unsigned short)s;
             });
         });
         __syncthreads();
@@ -619,7 +629,11 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   point appended) | cntL[n_s] int (pairs per layer) | excL[n_s] int, first_ex[2] int (abort
 //   bookkeeping of layers without a barrier) | recL[n_s] u32 | offL[n_s] u16 (first pair of the layer)
 //   | laySorted[n_s] u8 (padded to 4) | locL[n_s] u8 (padded to 4: layers that need no exchange)
-//   | runL[n_s] u8 (padded to 4) | idx8[n_s*n_l] u8
+//   | runL[n_s] u8 (padded to 4) | rowL[n_s] u8 (padded to 4: the layer's predecessor row, 0xff: none)
+//   | pair_lay[cap] u16 (padded to 4: layer of every stored pair) | idx8[idx_rows*n_l] u8 (padded to 8)
+//   | lrow[n_lp] double (the shared lateral row) | wmask[nt] u64 (per wave: lanes hit, per layer of a run)
+// Predecessor rows are kept only for layers that looked at other lanes (the others keep every
+// lane), handed out in the order the layers are relaxed; a.idx_rows of them fit.
 // SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
 // COUNT: measurement build that also adds the number of edges it priced to *a.n_evaluated
 template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
@@ -653,8 +667,14 @@ __global__ void sl_plan_kernel(SlDev a)
     unsigned char *laySorted = (unsigned char *)(offL + n_sm + (n_sm & 1));
     unsigned char *locL = laySorted + ((n_sm + 3) & ~3); // 1: the layer is relaxed without looking at other lanes
     unsigned char *runL = locL + ((n_sm + 3) & ~3); // the layer's sample count if it and its successor need no exchange, else 0
-    unsigned char *idx8 = runL + ((n_sm + 3) & ~3);
+    unsigned char *rowL = runL + ((n_sm + 3) & ~3);
+    unsigned short *pair_lay = (unsigned short *)(rowL + ((n_sm + 3) & ~3));
+    unsigned char *idx8 = (unsigned char *)(pair_lay + cap + (cap & 1));
+    // (offsets from smem, so that the pointer stays an LDS pointer)
+    double *lrow = (double *)((char *)smem + (((size_t)((char *)idx8 - (char *)smem) + (size_t)a.idx_rows * n_l + 7) & ~(size_t)7));
+    unsigned long long *wmask = (unsigned long long *)(lrow + n_lp);
 
+    if (a.retry_only && a.status[b] != SL_RETRY) return; // second launch: only what the first left open
     if (n_s <= 0) { // nothing to plan for this scenario
         write_skipped(a, b, n_sm, n_l);
         return;
@@ -688,6 +708,7 @@ __global__ void sl_plan_kernel(SlDev a)
         laySorted[s] = 1;
         locL[s] = 0;
         runL[s] = 0;
+        rowL[s] = 0xff;
         cntL[s] = 0;
         excL[s] = 0;
         if (g.K >= 0) {
@@ -699,6 +720,8 @@ __global__ void sl_plan_kernel(SlDev a)
             layW[s] = (c.cSH > 0.0 && c.Q <= 1e5 * c.cSH) ? (1.0 + 1e-9) / (c.cSH * (1.0 - 1e-9)) : 0.0;
         }
     }
+    if (!rstride)
+        for (int i = tid; i < n_l; i += nt) lrow[i] = lbase[i]; // the lateral row every layer shares (for the runs below)
     const bool layers_ascend = !__syncthreads_or(out_of_order);
     {
         // largest |l - mid| over the lattice (bounds every straight-edge cost)
@@ -735,7 +758,7 @@ __global__ void sl_plan_kernel(SlDev a)
     ps.has_ob = has_ob; ps.my_os = my_os; ps.my_ol = my_ol;
     ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
     ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL; ps.recL = recL;
-    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
+    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2; ps.lay = pair_lay;
     ps.count();
     __syncthreads();
     if (tid == 0) lc_all[0] = make_double2(ego_l, 0.0); // layer 0: the ego is the only source
@@ -790,6 +813,8 @@ __global__ void sl_plan_kernel(SlDev a)
     double c_top = MP_INF;  // upper bound of every accumulated cost of the layer being relaxed
     double cost_own = 0.0;  // this thread's node of the previous layer
     bool local = false;     // the layer being relaxed needs no exchange between lanes
+    int row_next = 0;       // predecessor rows handed out so far
+    bool rows_short = false; // a layer that walked found no row left: the path cannot be traced back here
     auto is_local = [&](double top, double w_inv_l) {
         return gap2_min > 0.0 && w_inv_l > 0.0 && (top + 1e-12 * (g_max + top)) * w_inv_l < gap2_min;
     };
@@ -802,8 +827,6 @@ __global__ void sl_plan_kernel(SlDev a)
             // layer in front of one that walks, the last layer) leave the run and take the
             // general path below.
             const int s_in = s;
-            unsigned rec_n = recL[s];
-            int k_n = runL[s];
             const int k_run = __builtin_amdgcn_readfirstlane(g_K);
             // the two sums a layer can add to this lane's cost, rounded as the general path
             // rounds them (edge first, then edge + cost)
@@ -813,52 +836,110 @@ __global__ void sl_plan_kernel(SlDev a)
             // which its own cost was still within the threshold, and the wave looks at the
             // counts once, behind the run.
             int n_within = 0;
-            while (true) {
-                const unsigned rec = __builtin_amdgcn_readfirstlane(rec_n);
-                const int k = __builtin_amdgcn_readfirstlane(k_n);
-                if (k != k_run || k == 0 || rec == ~0u) break;
-                rec_n = recL[s + 1]; // k != 0: layer s + 1 exists
-                k_n = runL[s + 1];
-                const int ne = (int)(rec >> 16), off = (int)(rec & 0xffffu);
-                // pair_hit at dl = 0 (the sample sits on this lane), four pairs per round trip
-                // to LDS: slots behind the layer's pairs are read (they lie inside the store
-                // or the arrays behind it) and ignored
-                const double *po = pair_ol + off, *pd = pair_ds2 + off;
-                bool hit = false;
-                if (ne > 0) {
-                    const double o0 = po[0], o1 = po[1], o2 = po[2], o3 = po[3];
-                    const double q0 = pd[0], q1 = pd[1], q2 = pd[2], q3 = pd[3];
-                    const double d0 = l_cur - o0, d1 = l_cur - o1, d2 = l_cur - o2, d3 = l_cur - o3;
-                    hit = fma(d0, d0, q0) < r2;
-                    hit |= (ne > 1) & (fma(d1, d1, q1) < r2);
-                    hit |= (ne > 2) & (fma(d2, d2, q2) < r2);
-                    hit |= (ne > 3) & (fma(d3, d3, q3) < r2);
-                    for (int e = 4; e < ne; ++e) {
-                        const double d = l_cur - po[e];
-                        hit |= fma(d, d, pd[e]) < r2;
+            // How far the run goes (at most 64 layers a time): lane i looks at layer s + i and
+            // keeps that layer's record (pairs << 16 | first pair), so that the loops below get
+            // every layer's record with a lane read instead of an LDS round trip.
+            int n_run;
+            unsigned rec_q = ~0u;
+            {
+                const int q = s + (tid & (MP_WAVE - 1));
+                int k_q = 0;
+                if (q < n_s) {
+                    rec_q = recL[q];
+                    k_q = runL[q];
+                }
+                const unsigned long long ok = __ballot(k_q == k_run && k_q != 0 && rec_q != ~0u);
+                n_run = __builtin_amdgcn_readfirstlane(ok == ~0ull ? MP_WAVE : __builtin_ctzll(~ok));
+            }
+            if (n_run > 0) {
+                // What happens to a lane in these layers does not depend on the other lanes or
+                // on the costs: its straight edge either passes an obstacle or not.  So the
+                // pairs of ALL layers of the run are looked at first (they lie in the store
+                // layer after layer), giving per layer the lanes that hit something; the costs
+                // then follow from those masks, in registers.  pair_hit at dl = 0: the sample
+                // sits on this lane.
+                const unsigned rec_first = __builtin_amdgcn_readlane(rec_q, 0);
+                const unsigned rec_last = __builtin_amdgcn_readlane(rec_q, n_run - 1);
+                const int e_begin = (int)(rec_first & 0xffffu);
+                const int e_end = (int)(rec_last & 0xffffu) + (int)(rec_last >> 16);
+                // Which lanes a pair hits: the lanes whose offset lies close enough to the
+                // obstacle's, and since the row ascends and every rounding step of the test
+                // fma(d, d, ds2) < r2, d = l - ol, is monotone in |d|, these are consecutive
+                // lanes around the obstacle.  So a lane takes a PAIR (not every lane every
+                // pair): it finds the first lane at or beyond the obstacle, tests the two lanes
+                // next to the obstacle (if neither is hit, none is), bisects for the first and
+                // the last lane hit with that very test, and ORs the range into the mask of
+                // the pair's layer.  Every wave does this for its own 64 lanes, in its own
+                // masks, so the waves need not meet.
+                const int lane = tid & (MP_WAVE - 1), lane0 = tid - lane; // first lattice lane of this wave
+                unsigned long long *wm = wmask + lane0;
+                wm[lane] = 0ull;
+                for (int e = e_begin + lane; e < e_end; e += MP_WAVE) {
+                    const double ol_e = pair_ol[e], q_e = pair_ds2[e];
+                    const int li = (int)pair_lay[e] - s_in;
+                    auto pred = [&](int i) {
+                        const double d = lrow[i] - ol_e;
+                        return fma(d, d, q_e) < r2;
+                    };
+                    int c0 = 0, c1 = n_l; // first lane whose offset is not below the obstacle's
+                    while (c0 < c1) {
+                        const int mid = (c0 + c1) >> 1;
+                        if (lrow[mid] < ol_e) c0 = mid + 1; else c1 = mid;
+                    }
+                    int in = -1;
+                    if (c0 < n_l && pred(c0)) in = c0;
+                    else if (c0 > 0 && pred(c0 - 1)) in = c0 - 1;
+                    if (in < 0) continue;
+                    int a0 = 0, a1 = in, b0 = in, b1 = n_l - 1; // first hit in [a0, a1], last hit in [b0, b1]
+                    while (a0 < a1 || b0 < b1) {
+                        if (a0 < a1) {
+                            const int mid = (a0 + a1) >> 1;
+                            if (pred(mid)) a1 = mid; else a0 = mid + 1;
+                        }
+                        if (b0 < b1) {
+                            const int mid = (b0 + b1 + 1) >> 1;
+                            if (pred(mid)) b0 = mid; else b1 = mid - 1;
+                        }
+                    }
+                    // lanes a0 .. b0 of the lattice, as bits of this wave's 64
+                    const int lo = max(a0 - lane0, 0), hi = min(b0 - lane0, MP_WAVE - 1);
+                    if (lo <= hi) {
+                        const unsigned long long m = (~0ull >> (MP_WAVE - 1 - (hi - lo))) << lo;
+                        atomicOr(&wm[li], m);
                     }
                 }
-                cost_own = (hit ? step_hit : step_free) + cost_own;
-                n_within += !(cost_own > abort_thr);
-                if (MAPS && is_target) {
-                    const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
-                    if (a.cost_map) a.cost_map[o] = cost_own;
-                    if (a.index_map) a.index_map[o] = tid;
+                // lane i now reads the mask of layer s + i; the loop below fetches it lane by lane
+                const unsigned long long wm_i = wm[lane];
+                const unsigned wm_lo = (unsigned)wm_i, wm_hi = (unsigned)(wm_i >> 32);
+                const unsigned long long my_bit = 1ull << lane;
+                for (int i = 0; i < n_run; ++i) {
+                    // (the lane read returns a signed int: through unsigned, or bit 31 would spread)
+                    const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)wm_lo, i);
+                    const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)wm_hi, i);
+                    const bool hit = (((unsigned long long)m_lo | ((unsigned long long)m_hi << 32)) & my_bit) != 0ull;
+                    cost_own = (hit ? step_hit : step_free) + cost_own;
+                    n_within += !(cost_own > abort_thr);
+                    if (MAPS && is_target) {
+                        const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
+                        if (a.cost_map) a.cost_map[o] = cost_own;
+                        if (a.index_map) a.index_map[o] = tid;
+                    }
+                    if constexpr (COUNT) {
+                        if (is_target) ++n_eval;
+                        n_eval_seen = n_eval;
+                        if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, 1ull);
+                    }
+                    ++s;
                 }
-                if constexpr (COUNT) {
-                    if (is_target) ++n_eval;
-                    n_eval_seen = n_eval;
-                    if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, 1ull);
-                }
-                ++s;
             }
             if (s != s_in) {
                 // the run's first layer at which every target of this wave was above the threshold
                 int last_within = is_target ? n_within : 0;
                 for (int m = 32; m >= 1; m >>= 1) last_within = max(last_within, __shfl_xor(last_within, m, MP_WAVE));
-                if ((tid & (MP_WAVE - 1)) == 0)
-                    for (int q = s_in + last_within; q < s; ++q)
-                        if (atomicAdd(&excL[q], 1) == nw - 1) atomicMin(first_ex, q);
+                // (lane i reports for layer s_in + i: the run holds at most 64 layers)
+                const int q = s_in + (int)(tid & (MP_WAVE - 1));
+                if (q >= s_in + last_within && q < s)
+                    if (atomicAdd(&excL[q], 1) == nw - 1) atomicMin(first_ex, q);
             }
             if (s != s_in) { // back to the general path at layer s (still one that needs no exchange)
                 done = s;
@@ -987,12 +1068,14 @@ __global__ void sl_plan_kernel(SlDev a)
         if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
         if (s == 1) c_top = (c_top + g_max + pen) * (1.0 + 1e-12); // bound of layer 2
         const bool next_local = s >= 1 && s + 1 < n_s && (s == 1 ? is_local(c_top, nxt.w_inv) : locL[s + 1] != 0);
+        // a layer that looked at other lanes keeps its predecessors (layer 0 has none: the ego);
+        // whether it did is this very flag, so the trace back and the store cannot disagree
+        const bool wants_row = s >= 1 && !local;
+        const bool store_row = wants_row && row_next < a.idx_rows;
+        rows_short |= wants_row && !store_row;
+        if (store_row && tid == 0) rowL[s] = (unsigned char)row_next;
         if (is_target) {
-            // (a layer without exchange keeps every lane: bj == tid.  It is stored all the same:
-            // whether the backtrack reads the row is decided by locL, whose bound is not the one
-            // `local` was derived from, and the two may disagree by a rounding error's width.
-            // Only the layers of the run loop above, which locL and runL agree on, skip the store.)
-            idx8[(size_t)s * n_l + tid] = (unsigned char)bj;
+            if (store_row) idx8[(size_t)row_next * n_l + tid] = (unsigned char)bj;
             const size_t o = ((size_t)b * n_sm + s) * n_l + tid;
             if (a.cost_map) a.cost_map[o] = best;
             if (a.index_map) a.index_map[o] = (s == 0) ? -1 : bj;
@@ -1001,6 +1084,7 @@ __global__ void sl_plan_kernel(SlDev a)
             if (!next_local) lc_all[(buf ^ 1) * n_lp + tid] = make_double2(l_cur, best);
             cost_own = best;
         }
+        row_next += store_row;
         if (next_local) {
             // no minimum and no barrier: the abort test of this layer (every cost above the
             // threshold) is kept as a count of the waves for which it holds
@@ -1058,6 +1142,8 @@ __global__ void sl_plan_kernel(SlDev a)
             }
         }
     }
+    // a plan whose path cannot be traced back with the rows at hand is left to the second launch
+    if (status == MP_SL_FOUND && rows_short) status = SL_RETRY;
     // rows that were never relaxed keep the reference's initial values
     for (int i = done * n_l + tid; i < n_sm * n_l; i += nt) {
         size_t o = (size_t)b * n_sm * n_l + i;
@@ -1080,7 +1166,8 @@ __global__ void sl_plan_kernel(SlDev a)
                 int end_l = i;
                 pidx[n_s - 1] = end_l;
                 for (int q = n_s - 1; q >= 1; --q) {
-                    if (!locL[q]) end_l = idx8[(size_t)q * n_l + end_l];
+                    const int r = rowL[q]; // 0xff: the layer kept every lane
+                    if (r != 0xff) end_l = idx8[(size_t)r * n_l + end_l];
                     pidx[q - 1] = end_l;
                 }
             }
@@ -1283,7 +1370,7 @@ __global__ void sl_plan_narrow_kernel(SlDev a)
     ps.my_ol = ps.has_ob ? ob_l[tid] : 0.0;
     ps.ego_s = ego_s; ps.d_s = d_s; ps.r = r; ps.r2 = r2;
     ps.layP2 = layP2; ps.layK = layK; ps.cntL = cntL; ps.offL = offL; ps.recL = nullptr;
-    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2;
+    ps.h0 = pair_h0; ps.ol = pair_ol; ps.ds2 = pair_ds2; ps.lay = nullptr;
     ps.count();
     __syncthreads();
     auto layer_geo = [&](int s) {
@@ -1749,11 +1836,15 @@ __global__ void sl_dp_kernel(int n_sm, int n_l, const int32_t *n_layers, const d
 // ---------------------------------------------------------------------------
 extern void mp_set_error(const char *fmt, ...);
 
-static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap)
+// rows: predecessor rows the kernel keeps (one per layer that walks; all n_s in the full-table form)
+static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap, int rows)
 {
     size_t d = (size_t)4 * ((n_l + 1) & ~1) + 5 * (size_t)n_s + 3 * (size_t)cap + 24;
     size_t bytes = d * sizeof(double) + (4 * (size_t)n_s + 2) * sizeof(int) + ((size_t)n_s + (n_s & 1)) * sizeof(short);
-    bytes += 3 * (((size_t)n_s + 3) & ~(size_t)3) + (size_t)n_s * n_l;
+    bytes += 4 * (((size_t)n_s + 3) & ~(size_t)3) + (size_t)rows * n_l;
+    bytes += 2 * ((size_t)cap + (cap & 1));                     // layer of every stored pair
+    bytes = (bytes + 7) & ~(size_t)7;
+    bytes += ((size_t)((n_l + 1) & ~1) + (size_t)((n_l + 63) / 64) * 64) * sizeof(double); // lateral row, run masks
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -1863,6 +1954,8 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.best_cost = best_cost;
     a.edge_cost = nullptr;
     a.pair_cap = 0;
+    a.idx_rows = 0;
+    a.retry_only = 0;
     a.n_evaluated = n_evaluated;
     a.order = nullptr;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
@@ -1914,23 +2007,40 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     // fewer if LDS would not hold it; layers past its end test their pairs directly
     const int threads = ((n_l + 63) / 64) * 64;
     const bool shared_row = batch->l_rstride == 0;
+    const bool maps = cost_map || index_map;
+    // Predecessor rows in LDS.  With one lateral row for all layers only the first few layers
+    // look at other lanes (the rest keep every lane and need no row), so the plain instance
+    // holds SL_ROWS_COMPACT rows: at 64 layers x 128 lanes that is 2 KB instead of 8, and the
+    // CU holds the workgroups its registers allow.  A scenario in which more layers walk is
+    // planned again by a second launch with every row in LDS (only such scenarios do anything
+    // in it).  The other instances (maps written, counting, a lateral grid per layer: every
+    // layer may walk) keep every row.
+    const int rows_compact = mp_knob_sl_rows() > 0 ? mp_knob_sl_rows() : SL_ROWS_COMPACT; // tests: force the second launch
+    const bool compact = shared_row && !maps && !n_evaluated && n_s > rows_compact;
+    const int rows = compact ? rows_compact : n_s;
     int cap = (7 * batch->ob_stride) / 2;
     if (mp_knob_sl_pair_cap() >= 0) cap = mp_knob_sl_pair_cap(); // tests: force the overflow path
     else {
         // registers allow 16 waves per CU; a store that lets LDS hold fewer workgroups than
         // that costs more (idle SIMDs) than laying a smaller store out again every few layers
-        const size_t budget = (size_t)10 * 1024 * (threads / 64), fixed = sl_plan_lds_bytes(n_s, n_l, 0);
-        const int fit = budget > fixed ? (int)((budget - fixed) / (3 * sizeof(double))) : 0;
+        const size_t budget = (size_t)10 * 1024 * (threads / 64), fixed = sl_plan_lds_bytes(n_s, n_l, 0, rows);
+        const int fit = budget > fixed ? (int)((budget - fixed) / (3 * sizeof(double) + 2)) : 0;
         const int floor_cap = 128;
         if (cap > fit) cap = fit > floor_cap ? fit : (cap < floor_cap ? cap : floor_cap);
     }
     cap = cap < 2 ? 2 : (cap > 16384 ? 16384 : cap);
     cap &= ~1;
-    while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
+    while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap, rows) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
     a.pair_cap = cap;
-    const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap);
+    a.idx_rows = rows;
+    a.retry_only = 0;
+    const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap, rows);
     if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
-    const bool maps = cost_map || index_map;
+    // the second launch of the compact form: every row in LDS, a store sized for what is left
+    int cap_full = cap;
+    while (cap_full > 2 && sl_plan_lds_bytes(n_s, n_l, cap_full, n_s) > 60 * 1024) cap_full = (cap_full / 2 + 1) & ~1;
+    const size_t lds_full = sl_plan_lds_bytes(n_s, n_l, cap_full, n_s);
+    if (lds_full > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(batch->B), block(threads);
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && !n_evaluated && batch->B > MP_ORDER_MIN_BATCH && mp_knob_order() != 0) {
@@ -1942,8 +2052,16 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     if (n_evaluated) {
         if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, false, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((sl_plan_kernel<false, false, true>), grid, block, lds, st, a);
-    } else if (shared_row && !maps) hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds, st, a);
-    else if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, true>), grid, block, lds, st, a);
+    } else if (shared_row && !maps) {
+        hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds, st, a);
+        if (compact) {
+            a.order = nullptr;
+            a.pair_cap = cap_full;
+            a.idx_rows = n_s;
+            a.retry_only = 1;
+            hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds_full, st, a);
+        }
+    } else if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, true>), grid, block, lds, st, a);
     else if (!maps) hipLaunchKernelGGL((sl_plan_kernel<false, false>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((sl_plan_kernel<false, true>), grid, block, lds, st, a);
     return launch_check("mp_sl_plan");
@@ -1973,6 +2091,8 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     a.best_cost = nullptr;
     a.edge_cost = edge_cost;
     a.pair_cap = 0;
+    a.idx_rows = 0;
+    a.retry_only = 0;
     a.n_evaluated = nullptr;
     a.order = nullptr;
     hipStream_t st = (hipStream_t)stream;
