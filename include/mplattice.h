@@ -151,8 +151,10 @@ int mp_sl_plan_ordered(const mp_sl_batch *batch, const mp_sl_params *params, dou
  * it actually prices -- exact pruning skips most of the n_l + (n_s-1)*n_l^2 edges
  * of a plan -- and ADDS that count, summed over the batch, to n_evaluated[0];
  * n_evaluated[1] receives the edges priced one after the other (the busiest lane
- * of every wave, layer by layer), which is what the kernel's time follows
- * (n_evaluated: two device uint64 the caller zeroes).  Lattices of more than 16 lanes only (the
+ * of every wave, layer by layer), which is what the kernel's time follows;
+ * n_evaluated[2] the turns of the walk over the sources and n_evaluated[3] the
+ * collision tests in them, each again for the busiest lane of every wave
+ * (n_evaluated: four device uint64 the caller zeroes).  Lattices of more than 16 lanes only (the
  * narrow kernel prices every edge).  Results are identical to mp_sl_plan's. */
 int mp_sl_plan_counted(const mp_sl_batch *batch, const mp_sl_params *params, int32_t *path_idx,
                        int32_t *status, int32_t *layers_done, double *best_cost, uint64_t *n_evaluated,

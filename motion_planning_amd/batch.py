@@ -128,12 +128,13 @@ def sl_plan_counted(batch, params=None, out=None):
     synchronises."""
     params = params or sl_params(n_l=batch.n_l)
     out = out or SLPlanOut(batch.B, batch.n_s, batch.n_l, False)
-    n_eval = torch.zeros(2, dtype=torch.int64, device=batch.s_layers.device)
+    n_eval = torch.zeros(4, dtype=torch.int64, device=batch.s_layers.device)
     cs = batch.c_struct()
     check(lib().mp_sl_plan_counted(C.byref(cs), C.byref(params), _p(out.path_idx), _p(out.status),
                                    _p(out.layers_done), _p(out.best_cost), _p(n_eval), _stream()),
           "mp_sl_plan_counted")
     n_eval = n_eval.cpu()
+    out.walk_turns, out.walk_tests = int(n_eval[2]), int(n_eval[3])   # busiest lane of every wave, layer by layer
     return out, int(n_eval[0]), int(n_eval[1])
 
 

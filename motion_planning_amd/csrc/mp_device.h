@@ -59,6 +59,17 @@ __device__ __forceinline__ double dpp_all_f64(double v)
 // broadcasts across rows, then lane 63 is read back; no LDS traffic.
 // Costs are never NaN, so v_min_f64 stands in for compare-and-select.  Every lane of
 // the wave must be active (a DPP move from an inactive lane reads 0).
+// A value every lane of the wave holds alike, moved to scalar registers: values read from LDS
+// or produced by a wave reduction sit in vector registers even when they are the same in all
+// lanes, and a kernel short of vector registers spills to memory what it could keep there.
+__device__ __forceinline__ double uni_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ double wave_min_f64(double v)
 {
     v = __builtin_fmin(dpp_all_f64<MP_DPP_QUAD_1032>(v), v);

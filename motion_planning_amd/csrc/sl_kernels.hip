@@ -195,12 +195,14 @@ struct Collider {
     LayerGeom g;
     double p1s, p2s, d_s, r2;
     int n_ent, n_ob;
+    mutable int last; // NE == -1: the pair that hit last time (-1: none yet), tried first the next time
     __device__ __forceinline__ void init(const double *eh, const double *eo, const double *ed, int ne,
                                          const LayerGeom &g_, double p1s_, double p2s_, double d_s_,
                                          const double *obs, const double *obl, int nob, double r2_)
     {
         e_h0 = eh; e_ol = eo; e_ds2 = ed; n_ent = ne;
         g = g_; p1s = p1s_; p2s = p2s_; d_s = d_s_; ob_s = obs; ob_l = obl; n_ob = nob; r2 = r2_;
+        last = -1;
         if constexpr (NE > 0) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
@@ -218,11 +220,18 @@ struct Collider {
 #pragma unroll
             for (int e = 0; e < NE; ++e) h |= pair_hit(l1, dl, h0[e], ol[e], ds2[e], r2);
         } else if constexpr (NE == -1) {
+            // A walk along a blocked stretch of sources meets the same obstacle edge after edge:
+            // the pair that hit last time is tried first, and only a miss looks at the list.
+            if (last >= 0 && pair_hit(l1, dl, e_h0[last], e_ol[last], e_ds2[last], r2)) return true;
             // in blocks of 8, so that a wave whose edges have all hit something stops early
             // (crowded layers have hundreds of pairs)
             for (int e0 = 0; e0 < n_ent && !h; e0 += 8) {
                 const int e1 = e0 + 8 < n_ent ? e0 + 8 : n_ent;
-                for (int e = e0; e < e1; ++e) h |= pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2);
+                for (int e = e0; e < e1; ++e)
+                    if (pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2)) {
+                        h = true;
+                        last = e;
+                    }
             }
         } else if constexpr (NE == -2) {
             const double T = p2s - p1s;
@@ -485,7 +494,8 @@ struct SrcSh {
 template <int NE, bool BOUND_FIRST = false, bool COUNT = false>
 __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, double l2v, double Q, double w_inv,
                                                double m_prev, double g_max, bool sorted, double pen,
-                                               const Collider<NE> &col, int *bj_out, int *n_eval = nullptr)
+                                               const Collider<NE> &col, int *bj_out, int *n_eval = nullptr,
+                                               int *n_visit = nullptr, int *n_test = nullptr)
 {
     const int l2 = threadIdx.x;
     const int j0 = min(l2, n_src - 1);
@@ -528,6 +538,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             // the collision test first: a candidate that hits pays the penalty, and where its
             // own cost plus the penalty already leaves no room (a blocked target walking along
             // a blocked stretch of sources) the closed form is not needed
+            if constexpr (COUNT) ++*n_test;
             hit = col.hit(l1, dl);
             if (hit && w_inv > 0.0) {
                 double gap = (best - cp) - pen * (1.0 - 1e-12);
@@ -565,6 +576,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     // the window) before the far side of a blocked stretch has been walked
     int jd = j0 - 1, ju = j0 + 1;
     while (jd >= 0 || ju < n_src) {
+        if constexpr (COUNT) ++*n_visit;
         if (jd >= 0) {
             lc = src.lc[jd];
             const double dl = l2v - lc.x;
@@ -639,7 +651,7 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
 __global__ void sl_plan_kernel(SlDev a)
 {
-    int n_eval = 0, n_eval_seen = 0;
+    int n_eval = 0, n_eval_seen = 0, n_visit = 0, n_test = 0; // COUNT build only
     if (!MAPS) a.cost_map = nullptr, a.index_map = nullptr;
     extern __shared__ double smem[];
     const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
@@ -765,9 +777,10 @@ __global__ void sl_plan_kernel(SlDev a)
     ps.place(0);
     double u_max = red[0];
     for (int w = 1; w < nw; ++w) u_max = red[w] > u_max ? red[w] : u_max;
-    const double g_max = cG * (double)MP_SL_K_CAP * u_max * u_max;
+    const double g_max = uni_f64(cG * (double)MP_SL_K_CAP * u_max * u_max);
     double gap_min = redmax[0];
     for (int w = 1; w < nw; ++w) gap_min = redmax[w] < gap_min ? redmax[w] : gap_min;
+    gap_min = uni_f64(gap_min);
     // Layers that need no exchange between lanes.  With one lateral row shared by all layers
     // (ascending, no two lanes equal) a target's own lane is its first candidate, a straight
     // edge that costs at most g_max + pen, so after layer s no cost exceeds
@@ -795,16 +808,17 @@ __global__ void sl_plan_kernel(SlDev a)
         bool sorted;
         double p2s, Q, w_inv, A, mid;
     } cur, nxt;
+    // (every lane reads the same words: into scalar registers, see uni_f64)
     auto load_layer = [&](int s, LayerRegs &L) {
-        L.kn = layK[s];
-        L.n_pairs = cntL[s];
-        L.pair_off = offL[s];
-        L.sorted = s == 0 || laySorted[rstride ? s - 1 : 0] != 0;
-        L.p2s = layP2[s];
-        L.Q = layQ[s];
-        L.w_inv = layW[s];
-        L.A = layA[s];
-        L.mid = layMid[s == 0 ? n_s - 1 : s - 1]; // layer 0: the last row's centre, as index -1 picks it
+        L.kn = uni_i32(layK[s]);
+        L.n_pairs = uni_i32(cntL[s]);
+        L.pair_off = uni_i32(offL[s]);
+        L.sorted = s == 0 || uni_i32(laySorted[rstride ? s - 1 : 0]) != 0;
+        L.p2s = uni_f64(layP2[s]);
+        L.Q = uni_f64(layQ[s]);
+        L.w_inv = uni_f64(layW[s]);
+        L.A = uni_f64(layA[s]);
+        L.mid = uni_f64(layMid[s == 0 ? n_s - 1 : s - 1]); // layer 0: the last row's centre, as index -1 picks it
     };
     load_layer(0, cur);
     double p1s = ego_s;
@@ -953,7 +967,7 @@ __global__ void sl_plan_kernel(SlDev a)
             // largest cost of layer 0, from which the bound c_top grows
             double top0 = redmax[0];
             for (int w = 1; w < nw; ++w) top0 = redmax[w] > top0 ? redmax[w] : top0;
-            c_top = top0 < MP_INF ? (top0 + g_max + pen) * (1.0 + 1e-12) : MP_INF;
+            c_top = uni_f64(top0 < MP_INF ? (top0 + g_max + pen) * (1.0 + 1e-12) : MP_INF);
             local = false; // layer 1 still takes the walk (its minimum was reduced with layer 0's)
             // which of the later layers need no exchange: the bound grows by the same amount
             // per layer, so every layer's can be had now (read from layer 2's end on, behind
@@ -972,6 +986,7 @@ __global__ void sl_plan_kernel(SlDev a)
         if (s > 0 && !local) {
             m_prev = red[buf * 8];
             for (int w = 1; w < nw; ++w) m_prev = red[buf * 8 + w] < m_prev ? red[buf * 8 + w] : m_prev;
+            m_prev = uni_f64(m_prev);
             if (s >= 2 && m_prev > abort_thr) {
                 if (status == MP_SL_FOUND) status = MP_SL_NOT_FOUND;
                 if (a.p.early_exit) break;
@@ -1032,7 +1047,7 @@ __global__ void sl_plan_kernel(SlDev a)
         Collider<NE> col;                                                                                \
         col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);                    \
         best = relax_target<NE, false, COUNT>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col, &bj, \
-                                              &n_eval);                                                  \
+                                              &n_eval, &n_visit, &n_test);                               \
     }
             switch (ent_stored ? n_ent : -1) {
             case 0: SL_RELAX(0) break;
@@ -1048,7 +1063,7 @@ __global__ void sl_plan_kernel(SlDev a)
                     Collider<-1> col;
                     col.init(e_h0, e_ol, e_ds2, n_ent, geo, p1s, p2s, d_s, ob_s, ob_l, n_ob, r2);
                     best = relax_target<-1, true, COUNT>(n_src, src, l_cur, Q, w_inv, m_prev, g_max, sorted, pen, col,
-                                                         &bj, &n_eval);
+                                                         &bj, &n_eval, &n_visit, &n_test);
                 } else {
                     SL_RELAX(-1)
                 }
@@ -1059,10 +1074,19 @@ __global__ void sl_plan_kernel(SlDev a)
         if constexpr (COUNT) {
             // second counter: edges priced one after the other, i.e. the busiest lane of
             // every wave, layer by layer (what the wave's time follows)
-            int c = n_eval - n_eval_seen;
+            int c = n_eval - n_eval_seen, cv = n_visit, ct = n_test;
             n_eval_seen = n_eval;
-            for (int m = 32; m >= 1; m >>= 1) c = max(c, __shfl_xor(c, m, MP_WAVE));
-            if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) atomicAdd(a.n_evaluated + 1, (unsigned long long)c);
+            n_visit = n_test = 0;
+            for (int m = 32; m >= 1; m >>= 1) {
+                c = max(c, __shfl_xor(c, m, MP_WAVE));
+                cv = max(cv, __shfl_xor(cv, m, MP_WAVE));
+                ct = max(ct, __shfl_xor(ct, m, MP_WAVE));
+            }
+            if ((tid & (MP_WAVE - 1)) == 0 && a.n_evaluated) {
+                atomicAdd(a.n_evaluated + 1, (unsigned long long)c);
+                atomicAdd(a.n_evaluated + 2, (unsigned long long)cv); // turns of the walk, busiest lane
+                atomicAdd(a.n_evaluated + 3, (unsigned long long)ct); // collision tests in them, busiest lane
+            }
         }
         done = s + 1;
         if (s + 1 < n_s) load_layer(s + 1, nxt); // a refill of the pair store re-reads its two fields
