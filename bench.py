@@ -786,6 +786,35 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
                    "(7 M + 40) flop per point to Frenet, M = the scene's reference-line samples; the kernel "
                    "compares only the samples of the blocks whose bounding box can hold the nearest one"),
     ]
+    # reference-line tables: the reference integrates the arc length of every table entry from
+    # the origin anew (Curve.calc_arc_len): one integrand value sqrt(1 + y'^2) per d_x of arc
+    # plus one per spline piece crossed and the end point, ~19 flop each (quintic derivative in
+    # power form, square, add, root, running sum); twice, for the Frenet and the inverse table
+    n_kn = wsc["n_way"].astype(np.float64)
+    k_ori = np.clip(np.rint((a["origin"][:, 0].cpu().numpy() - a["tab_x"][:, 0].cpu().numpy()) / params.d_x), 0, None)
+    after = np.clip(M - k_ori, 0, None)                     # entries at or beyond the origin
+    evals = after * (after + 1) / 2.0 + after * (1.0 + (n_kn - 1) / 2.0)
+    flop_rl = float(np.sum((status != -5) * 2.0 * 19.0 * evals))
+    # blocked intervals: every path point against every obstacle on every time layer, 7 flop a test
+    n_path = a["n_path"].cpu().numpy().astype(np.float64)
+    flop_reg = float(np.sum(7.0 * n_t * (sc["n_st"] + sc["n_dy"]) * n_path))
+    roofs.append(stage_roof("reference-line tables", "refline_tables_kernel", flop_rl,
+                            "19 flop per arc-length integrand value, (k - k_origin) + pieces crossed + 1 values for "
+                            "table entry k as the reference integrates it from the origin anew, for the Frenet and "
+                            "the inverse table; the kernel shares the integrand values among the entries"))
+    # (the interval kernel scans a static obstacle once instead of on every time layer and drops
+    # obstacles that cannot reach the path's bounding box, so the reference's test count over its
+    # time would exceed the vector peak: its entry is priced by its own vector instructions)
+    reg = stage_roof("ST blocked intervals", "st_regions_once_kernel", flop_reg,
+                     "bound by vector instruction issue: frac = the kernel's own vector instructions "
+                     "(SQ_INSTS_VALU of the committed counter pass) / duration against 1024 SIMDs x 2.4 GHz / 4 "
+                     "cycles.  reference_work_tflops = 7 flop per distance test x n_t x (statics + moving) x path "
+                     "points as the reference scans them / duration: not a utilisation (the kernel scans a static "
+                     "obstacle once and drops obstacles that cannot reach the path's bounding box)")
+    reg.update(bound="valu_issue", unit="G wave-instructions/s", peak=ISSUE_PEAK_GINST,
+               reference_work_tflops=reg["achieved"], frac=reg.get("issue_slots_used"),
+               achieved=reg["issue_slots_used"] * ISSUE_PEAK_GINST if reg.get("issue_slots_used") else None)
+    roofs.append(reg)
     k = pmc.get("sl_plan_narrow_kernel", {})
     t_sl = stage_ms["SL path DP"] * 1e-3
     sl_entry = {"kernel": "sl_plan_narrow_kernel", "stage": "SL path DP", "kernel_ms": stage_ms["SL path DP"],

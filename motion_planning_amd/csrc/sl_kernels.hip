@@ -50,7 +50,6 @@ struct SlDev {
     unsigned long long *n_evaluated; // counting instance of the fused kernel only: edges priced, summed over the batch
     const int32_t *order;            // fused kernel: workgroup i plans scenario order[i] (null: scenario i)
     int32_t idx_rows;                // fused kernel: predecessor rows its LDS holds (one per layer that walks)
-    int32_t retry_only;              // fused kernel: plan only the scenarios whose status is SL_RETRY
 };
 
 // Internal status of the fused kernel's compact form (never leaves the library): the plan was
@@ -648,7 +647,9 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 // lane), handed out in the order the layers are relaxed; a.idx_rows of them fit.
 // SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
 // COUNT: measurement build that also adds the number of edges it priced to *a.n_evaluated
-template <bool SHARED_ROW, bool MAPS, bool COUNT = false>
+// RETRY: the second launch of the compact form (plans only the scenarios the first left open; an
+// instance of its own so that a profile tells the two launches apart)
+template <bool SHARED_ROW, bool MAPS, bool COUNT = false, bool RETRY = false>
 __global__ void sl_plan_kernel(SlDev a)
 {
     int n_eval = 0, n_eval_seen = 0, n_visit = 0, n_test = 0; // COUNT build only
@@ -686,7 +687,7 @@ __global__ void sl_plan_kernel(SlDev a)
     double *lrow = (double *)((char *)smem + (((size_t)((char *)idx8 - (char *)smem) + (size_t)a.idx_rows * n_l + 7) & ~(size_t)7));
     unsigned long long *wmask = (unsigned long long *)(lrow + n_lp);
 
-    if (a.retry_only && a.status[b] != SL_RETRY) return; // second launch: only what the first left open
+    if (RETRY && a.status[b] != SL_RETRY) return; // second launch: only what the first left open
     if (n_s <= 0) { // nothing to plan for this scenario
         write_skipped(a, b, n_sm, n_l);
         return;
@@ -1979,7 +1980,6 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     a.edge_cost = nullptr;
     a.pair_cap = 0;
     a.idx_rows = 0;
-    a.retry_only = 0;
     a.n_evaluated = n_evaluated;
     a.order = nullptr;
     // MP_SL_NARROW=0 sends narrow lattices through the one-thread-per-node kernel as
@@ -2057,7 +2057,6 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     while (cap > 2 && sl_plan_lds_bytes(n_s, n_l, cap, rows) > 60 * 1024) cap = (cap / 2 + 1) & ~1;
     a.pair_cap = cap;
     a.idx_rows = rows;
-    a.retry_only = 0;
     const size_t lds = sl_plan_lds_bytes(n_s, n_l, cap, rows);
     if (lds > 160 * 1024) { mp_set_error("mp_sl_plan: lattice too large for LDS"); return MP_E_UNSUPPORTED; }
     // the second launch of the compact form: every row in LDS, a store sized for what is left
@@ -2082,8 +2081,7 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
             a.order = nullptr;
             a.pair_cap = cap_full;
             a.idx_rows = n_s;
-            a.retry_only = 1;
-            hipLaunchKernelGGL((sl_plan_kernel<true, false>), grid, block, lds_full, st, a);
+            hipLaunchKernelGGL((sl_plan_kernel<true, false, false, true>), grid, block, lds_full, st, a);
         }
     } else if (shared_row) hipLaunchKernelGGL((sl_plan_kernel<true, true>), grid, block, lds, st, a);
     else if (!maps) hipLaunchKernelGGL((sl_plan_kernel<false, false>), grid, block, lds, st, a);
@@ -2116,7 +2114,6 @@ extern "C" int mp_sl_edge_cost(const mp_sl_batch *batch, const mp_sl_params *par
     a.edge_cost = edge_cost;
     a.pair_cap = 0;
     a.idx_rows = 0;
-    a.retry_only = 0;
     a.n_evaluated = nullptr;
     a.order = nullptr;
     hipStream_t st = (hipStream_t)stream;

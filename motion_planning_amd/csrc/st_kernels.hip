@@ -380,8 +380,15 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
                 const double2 chv = *(const double2 *)(ch_j - e);
                 const int h = __double2loint(chv.y);
+#ifdef ST_EXP_NOGATHER
+                // timing-only build (tools/st_conflicts.sh; results are wrong): both table reads at
+                // one address per cell, to see what their data-dependent addresses cost
+                const double av = *(const double *)(acc_j + (h & 0));
+                const double jv = *(const double *)(jerk_j + (h & 0));
+#else
                 const double av = *(const double *)(acc_j + (int)(short)(h & 0xffff));
                 const double jv = *(const double *)(jerk_j + (h >> 16));
+#endif
                 const double tot = __dadd_rn(__dadd_rn(base, av), jv);
                 const double c = __dadd_rn(tot, chv.x);
                 if (!FIRST) { if (c <= best) ST_CNT_LANE(9); else ST_CNT_LANE(10); }

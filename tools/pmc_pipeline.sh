@@ -6,7 +6,7 @@ out=${1:-gpurun_out/pmc_pipe}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --workload pipeline --steps 3 --warmup 1 --reps 1 --cpu-sample 0 --streams 1 > "$out.$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out.$name.log"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --workload pipeline --steps 3 --warmup 1 --reps 1 --cpu-sample 0 --single-plan 0 --streams 1 > "$out.$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out.$name.log"; exit 1; }
   echo "pass $name ok"
 }
 mkdir -p "$out"

@@ -22,8 +22,11 @@ for line in open(src):
     if name == "st_dp_r_kernel":
         name = "st_dp_kernel"   # the instances per interval bound are the same kernel body
     if name in KERNELS:
-        if m.group(1).startswith("sl_plan_kernel<") and m.group(1).rstrip(">").endswith(", true"):
-            continue   # the counting instance (third template argument) is not the product kernel
+        if m.group(1).startswith("sl_plan_kernel<"):
+            targs = [t.strip() for t in m.group(1)[len("sl_plan_kernel<"):].rstrip(">").split(",")]
+            if "true" in targs[2:]:
+                continue   # the counting instance (third argument) and the second launch of the compact
+                           # form (fourth) are not the product kernel's main launch
         k.setdefault(name, {})[m.group(2)] = float(m.group(3))
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles",
                    "pmc_pipeline_latest.json" if pipeline else "pmc_latest.json")
