@@ -888,7 +888,13 @@ __global__ void sl_plan_kernel(SlDev a)
                 // masks, so the waves need not meet.
                 const int lane = tid & (MP_WAVE - 1), lane0 = tid - lane; // first lattice lane of this wave
                 unsigned long long *wm = wmask + lane0;
-                wm[lane] = 0ull;
+                // The masks pass from the lanes that write them to the lanes that read them
+                // through LDS inside one wave: atomic accesses with fences of wave scope, so that
+                // the compiler neither keeps a lane's own zero in a register (a lane that takes
+                // no pair still reads what the others wrote) nor moves the accesses across.
+                __hip_atomic_store(&wm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 for (int e = e_begin + lane; e < e_end; e += MP_WAVE) {
                     const double ol_e = pair_ol[e], q_e = pair_ds2[e];
                     const int li = (int)pair_lay[e] - s_in;
@@ -924,7 +930,9 @@ __global__ void sl_plan_kernel(SlDev a)
                     }
                 }
                 // lane i now reads the mask of layer s + i; the loop below fetches it lane by lane
-                const unsigned long long wm_i = wm[lane];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long wm_i = __hip_atomic_load(&wm[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const unsigned wm_lo = (unsigned)wm_i, wm_hi = (unsigned)(wm_i >> 32);
                 const unsigned long long my_bit = 1ull << lane;
                 for (int i = 0; i < n_run; ++i) {

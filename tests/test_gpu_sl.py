@@ -757,3 +757,49 @@ def test_sl_lean_instance_with_few_predecessor_rows(rows, early_exit):
                 n_retry_shapes += int((np.count_nonzero(np.diff(path[found], axis=1), axis=1) > rows).any())
     if rows in (1, 2):
         assert n_retry_shapes > 0, "no scenario needed more rows than the forced count: the second launch never ran"
+
+
+@pytest.mark.parametrize("cap", [None, 16, 128])
+@pytest.mark.parametrize("n_ob", [2, 6, 20, 50])
+def test_sl_few_pairs_in_long_runs_of_layers_without_exchange(oracle, knob, n_ob, cap):
+    """On the benchmark's lattice all but the first few layers keep every lane and are taken
+    in runs of up to 64, whose (sample, obstacle) pairs are spread over the lanes of a wave.
+    With few obstacles a run has fewer pairs than layers, and with a small pair store a run
+    can start right behind a refill with a handful of pairs in it: the lanes that took no pair
+    still have to see what the others found for their layer.  Every instance against the
+    oracle."""
+    import torch
+    from motion_planning_amd import batch as mb
+    B = 24
+    s_layers, l_row, ego, ob_s, ob_l, n_obs, ob_dist = cfg3_batch(B, seed0=5000 + n_ob, n_ob=n_ob)
+    if n_ob == 50:
+        # the scenario whose refill at 128 slots leaves a run of five layers with four pairs
+        s_layers, l_row, ego, ob_s, ob_l, n_obs, ob_dist = cfg3_batch(B, seed0=1000 + 13691 - 3)
+    else:
+        ob_s[:, : n_ob // 2] = 30.0 + 0.66 * ob_s[:, : n_ob // 2]   # half of them well inside the runs
+    sb = mb.SLBatch(s_layers, l_row, ego, ob_s, ob_l, n_obs, ob_dist)
+    prm = mb.sl_params(early_exit=False, n_l=128)
+    if cap is not None:
+        knob("MP_SL_PAIR_CAP", cap)
+    full = mb.sl_plan(sb, prm, want_maps=True)
+    lean = mb.sl_plan(sb, prm, want_maps=False)
+    lean_unordered = mb.sl_plan(sb, prm, want_maps=False, ordered=False)
+    counted, _, _ = mb.sl_plan_counted(sb, prm)
+    torch.cuda.synchronize()
+    for o in (lean, lean_unordered, counted):
+        assert torch.equal(o.status, full.status) and torch.equal(o.path_idx, full.path_idx)
+        assert np.array_equal(o.best_cost.cpu().numpy(), full.best_cost.cpu().numpy(), equal_nan=True)
+
+    def reference(b):
+        s_map = np.repeat(s_layers[b][:, None], 128, axis=1)
+        l_map = np.broadcast_to(l_row[b], (64, 128))
+        return oracle.sl_find_path(s_map, l_map, 63, ego[b], np.stack([ob_s[b], ob_l[b]], 1), ob_dist[b],
+                                   no_early_exit=True)
+
+    with ThreadPoolExecutor(8) as pool:
+        refs = list(pool.map(reference, range(B)))
+    for b, ref in enumerate(refs):
+        got = dict(found=int(full.status[b]) == 1, cost_map=full.cost_map[b].cpu().numpy(),
+                   index_map=full.index_map[b].cpu().numpy(), path_idx=full.path_idx[b].cpu().numpy(),
+                   layers_done=int(full.layers_done[b]))
+        assert_sl_parity(got, ref)
