@@ -70,3 +70,46 @@ def test_rank7_shard_of_the_65536_scenario_split(oracle):
     assert torch.equal(u["layers_done"], out.layers_done.cpu()) and torch.equal(u["st_path"], st["path_s_ind"].cpu())
     assert torch.equal(u["st_len"], st["path_len"].cpu())
     assert np.array_equal(u["best_cost"].numpy(), best, equal_nan=True)
+
+
+def test_all_65536_scenarios_two_independent_gpu_paths_agree(knob):
+    """Every scenario of the configuration, not a sample: the fused SL kernel (pruned walk, runs
+    of layers without exchange, pair store in LDS) against the materialised path (every edge of
+    the lattice priced by the edge kernel into a tensor in HBM, then the plain DP over it), and
+    the lanes-per-cell ST DP against the thread-per-cell kernel.  Plans must agree bit for bit;
+    the oracle pins both paths on samples elsewhere, this pins the rare scenario."""
+    import torch
+    import bench
+    from motion_planning_amd import batch as mb
+    total, chunk = bench.CFG4_TOTAL, 2048          # 2048 edge tensors of 64 x 128 x 128 doubles: 17 GB
+    n_s, n_l = bench.N_S, bench.N_L
+    prm = mb.sl_params(early_exit=False, n_l=n_l)
+    n_found = 0
+    for lo in range(0, total, chunk):
+        sc = bench.make_scenarios(lo, chunk)
+        sb = mb.SLBatch(sc["s_layers"], sc["l_row"], sc["ego"], sc["ob_s"], sc["ob_l"], sc["n_ob"], sc["ob_dist"])
+        fused = mb.sl_plan(sb, prm, mb.SLPlanOut(chunk, n_s, n_l, want_maps=False))
+        edge, est = mb.sl_edge_cost(sb, prm)
+        plain = mb.sl_dp(edge, prm)
+        del edge
+        st_in = (sc["st_n_s"], sc["down"], sc["up"], sc["n_reg"], sc["cur_vel"], bench.SPEED_LIM)
+        st = mb.st_dp(*st_in, want_tables=False, n_s_max=bench.ST_N_S)
+        knob("MP_ST_GENERIC", 1)
+        st_plain = mb.st_dp(*st_in, want_tables=False, n_s_max=bench.ST_N_S)
+        knob("MP_ST_GENERIC", -1)
+        torch.cuda.synchronize()
+        assert bool((est == 1).all())
+        bad = ((fused.path_idx != plain.path_idx).any(1) | (fused.status != plain.status)).nonzero().flatten()
+        assert bad.numel() == 0, "SL plans differ for scenario ids %s" % (lo + bad[:8].cpu().numpy())
+        assert torch.equal(fused.layers_done, plain.layers_done)
+        # the instance that writes the maps (every predecessor row in LDS, a smaller pair store): its
+        # whole cost map and predecessor map against the plain DP's
+        maps = mb.sl_plan(sb, prm, want_maps=True)
+        assert torch.equal(maps.cost_map, plain.cost_map) and torch.equal(maps.index_map, plain.index_map)
+        assert torch.equal(maps.path_idx, plain.path_idx) and torch.equal(maps.status, plain.status)
+        del maps
+        assert np.array_equal(fused.best_cost.cpu().numpy(), plain.best_cost.cpu().numpy(), equal_nan=True)
+        bad = ((st["path_s_ind"] != st_plain["path_s_ind"]).any(1) | (st["path_len"] != st_plain["path_len"]))
+        assert not bool(bad.any()), "ST plans differ for scenario ids %s" % (lo + bad.nonzero().flatten()[:8].cpu().numpy())
+        n_found += int((fused.status == 1).sum())
+    assert 0 < n_found < total
