@@ -17,6 +17,8 @@
 // The whole file is compiled without floating-point contraction so that the
 // operation order written here (the reference's) is the order executed.
 #pragma clang fp contract(off)
+#include <atomic>
+
 #include "mp_device.h"
 #include "c2f_device.h"
 #include "plan_glue.h"
@@ -133,24 +135,31 @@ __device__ double arc_from_origin(const ArcCtx &c, double t1, int *bad)
     return c.arc_pre[en_i] + quintic_arc_len(c.coef + 6 * en_i, 0, en_t, c.dt, bad, c.ftab + RL_FT * en_i);
 }
 
-// One workgroup per scenario.  Dynamic LDS: tsum[m_max] (double) seg[m_max] (int).
+// Doubles of dynamic LDS per spline segment slot (ns = n_knots_max - 1 slots): T, seg_full, Tseq,
+// Scum (1 each), coef (6), ftab (RL_FT), and vv, aa, arc_pre with one slot more each.
+__host__ __device__ __forceinline__ size_t rl_seg_doubles(int ns) { return (size_t)ns * (10 + RL_FT) + 3 * ((size_t)ns + 1); }
+
+// One workgroup per scenario.  Dynamic LDS, sized by the batch's knot slots so that short
+// reference lines leave room for many workgroups per CU: the per-segment arrays (see
+// rl_seg_doubles), then tsum[m_max] (double) seg[m_max] (int).
 __global__ void refline_tables_kernel(RlDev a)
 {
     extern __shared__ double smem[];
-    __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], seg_full[RL_SEG_CAP];
-    __shared__ double vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
-    __shared__ double ftab[RL_SEG_CAP * RL_FT]; // arc-length integrand of every segment at 0, dt, 2dt, ...
-    __shared__ double Tseq[RL_SEG_CAP];         // running sums of T in segment order
-    __shared__ double Scum[RL_SEG_CAP];         // running end of the current segment in calc_point_arr's walk
-    __shared__ double arc_pre[RL_SEG_CAP + 1];  // arc length from the origin to the start of a segment
+    const int ns = min(a.n_knots_max - 1, RL_SEG_CAP); // (a line with more segments is refused below)
+    double *T = smem, *coef = T + ns, *seg_full = coef + 6 * ns;
+    double *vv = seg_full + ns, *aa = vv + ns + 1;
+    double *ftab = aa + ns + 1;        // arc-length integrand of every segment at 0, dt, 2dt, ...
+    double *Tseq = ftab + RL_FT * ns;  // running sums of T in segment order
+    double *Scum = Tseq + ns;          // running end of the current segment in calc_point_arr's walk
+    double *arc_pre = Scum + ns;       // arc length from the origin to the start of a segment
     __shared__ double arc0[RL_ARC_CAP];         // integrand values of the origin's piece
     __shared__ double red_c[16];
     __shared__ int red_i[16];
     __shared__ double sc_d[8]; // t_max, delta, first piece, s_end
     __shared__ int sc_i[8];    // M, n samples before the appended one, status, k_ori, ascending, parallel walk, start segment
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    double *tsum = smem;
-    int *seg = (int *)(smem + a.m_max);
+    double *tsum = arc_pre + ns + 1;
+    int *seg = (int *)(tsum + a.m_max);
     const int npts = a.n_knots[b];
     const int n = npts - 1;
     const double *kx = a.knots_x + (size_t)b * a.n_knots_max;
@@ -808,9 +817,24 @@ extern "C" int mp_refline_tables(int32_t B, const double *knots_x, const double 
     if (m_max > 4096) { mp_set_error("mp_refline_tables: m_max > 4096"); return MP_E_UNSUPPORTED; }
     RlDev a{n_knots_max, m_max, knots_x, knots_y, n_knots, vec, ego_xy, d_x, tab_x, tab_y, tab_s, tab_theta,
             tab_kappa, M, origin, status, inv_x, inv_s, inv_y, inv_theta, n_inv};
-    size_t lds = (size_t)m_max * (sizeof(double) + sizeof(int));
+    const int ns = n_knots_max - 1 < RL_SEG_CAP ? n_knots_max - 1 : RL_SEG_CAP; // lines with more segments report MP_RL_E_CAPACITY
+    size_t lds = rl_seg_doubles(ns) * sizeof(double) + (size_t)m_max * (sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
-    int threads = m_max <= 128 ? 128 : 256;
+    if (lds > 64 * 1024) { // long lines with many knot slots: beyond what a launch gets without asking
+        static std::atomic<size_t> allowed{0};
+        if (allowed.load(std::memory_order_relaxed) < lds) {
+            if (hipFuncSetAttribute((const void *)refline_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                mp_set_error("mp_refline_tables: %zu bytes of LDS per line are not available", lds);
+                return MP_E_UNSUPPORTED;
+            }
+            allowed.store(lds, std::memory_order_relaxed);
+        }
+    }
+    // A large batch fills the GPU with lines: one wave per line then (its barriers cost nothing
+    // and a CU holds four times as many lines); a small one wants its lines done soon.
+    int threads = B >= 1024 ? 64 : (m_max <= 128 ? 128 : 256);
     if (mp_knob_rl_threads() > 0) threads = mp_knob_rl_threads(); // development aid
     hipLaunchKernelGGL(refline_tables_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_refline_tables");

@@ -3,6 +3,7 @@ launch knobs (development aid): lanes per cell x workgroup size.
 
     python3 tools/time_st_lanes.py
 """
+import os
 import sys
 
 import numpy as np
@@ -35,6 +36,8 @@ def main():
         return out
 
     ref = timed("library's choice")
+    if os.environ.get("ST_AB_ONLY"):
+        return
     for thr in (128, 192, 256):
         for lanes in (4, 8):
             _lib.set_knob("MP_ST_THREADS", thr)
