@@ -28,9 +28,9 @@
  * MP_ST_GENERIC=1 (mp_st_dp through the kernel that holds every relaxation path
  * instead of the instance built for the batch's interval bound r_max),
  * MP_ORDER=0 (the *_ordered entry points launch in the caller's order),
- * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n (workgroup size of
- * mp_st_dp / mp_refline_tables / the front end of mp_plan_scenes; honoured only
- * when a multiple of 64 within 64..1024), MP_ST_LANES=4|8 (lanes that share a
+ * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n / MP_CV_THREADS=n (workgroup
+ * size of mp_st_dp / mp_refline_tables / the front end / the two spline stages of
+ * mp_plan_scenes; honoured only when a multiple of 64 within 64..1024), MP_ST_LANES=4|8 (lanes that share a
  * cell in mp_st_dp's relaxation), MP_SL_ROWS=n (predecessor rows mp_sl_plan's
  * kernel keeps in LDS before it leaves a scenario to its second launch).
  */

@@ -866,13 +866,20 @@ static int cv_lds_check(const char *what, const char *dim, int value, size_t lds
     return MP_E_UNSUPPORTED;
 }
 
+// Workgroup size of the spline stages: as many threads as there are points to evaluate, up to 256.
+static int cv_threads(int n_points)
+{
+    if (mp_knob_cv_threads() > 0) return mp_knob_cv_threads(); // development aid
+    return n_points <= 128 ? 128 : 256;
+}
+
 // The two fused stages of the whole replan (plan_glue.h).
 int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 {
     size_t lds = (size_t)a.p_max * (2 * sizeof(double) + sizeof(int));
     lds = (lds + 15) & ~(size_t)15;
     if (int rc = cv_lds_check("mp_plan_scenes (path spline)", "p_max", a.p_max, lds)) return rc;
-    hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(a.p_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(cv_threads(a.p_max)), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (path spline)");
 }
 
@@ -885,7 +892,10 @@ int mp_plan_tail_stage(int32_t B, const PlanTailDev &a, void *stream)
     if (int rc = cv_lds_check("mp_plan_scenes (speed profile and path points)", table_larger ? "m_max" : "q_max",
                               table_larger ? a.m_max : a.q_max, lds))
         return rc;
-    hipLaunchKernelGGL(plan_tail_kernel, dim3(B), dim3(a.q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
+    // (a few dozen points per scene and single-lane sections between them: in a large batch one
+    // wave per scene, whose barriers cost nothing, does better than two)
+    const int threads = (B >= 1024 && mp_knob_cv_threads() <= 0) ? MP_WAVE : cv_threads(a.q_max);
+    hipLaunchKernelGGL(plan_tail_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (speed profile and path points)");
 }
 

@@ -16,6 +16,7 @@ int mp_knob_st_regions_once();
 int mp_knob_st_threads();
 int mp_knob_rl_threads();
 int mp_knob_fe_threads();
+int mp_knob_cv_threads();
 int mp_knob_st_generic();
 int mp_knob_order(); // 0: the *_ordered entry points launch in the caller's order
 int mp_knob_sl_rows(); // predecessor rows of the fused SL kernel's compact form (tests: small values force its second launch)

@@ -814,8 +814,7 @@ __device__ __forceinline__ bool scan_path(const double *ps, const double *pl, in
 __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
 {
     extern __shared__ double smem[];
-    __shared__ int wave_cnt[16];
-    __shared__ int base_sh, n_work_sh;
+    __shared__ int n_work_sh, regs_sh;
     __shared__ double box_sh[4][16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (MP_WAVE - 1), wave = tid / MP_WAVE, nw = nt / MP_WAVE;
@@ -839,7 +838,7 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
     s_lo = wave_min_f64(s_lo); s_hi = -wave_min_f64(-s_hi);
     l_lo = wave_min_f64(l_lo); l_hi = -wave_min_f64(-l_hi);
     if (lane == 0) { box_sh[0][wave] = s_lo; box_sh[1][wave] = s_hi; box_sh[2][wave] = l_lo; box_sh[3][wave] = l_hi; }
-    if (tid == 0) n_work_sh = 0;
+    if (tid == 0) n_work_sh = regs_sh = 0;
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
         s_lo = box_sh[0][w] < s_lo ? box_sh[0][w] : s_lo; s_hi = box_sh[1][w] > s_hi ? box_sh[1][w] : s_hi;
@@ -881,46 +880,35 @@ __global__ void st_regions_once_kernel(RegDev a, int n_items_max)
         res_u[q] = u;
     }
     __syncthreads();
-    // per-layer lists in the reference's order: statics, then moving obstacles
-    int overflow = 0, regs_sum = 0;
+    // per-layer lists in the reference's order: statics, then moving obstacles.  A wave takes
+    // whole layers (a list is an ordered compaction of the layer's flags: ballots and a
+    // running count in the wave's own registers), so the waves do not meet until the end.
+    int overflow = 0, regs_loc = 0;
     const int n_ob = n_st + n_dy;
-    for (int i = 0; i < n_t; ++i) {
-        if (tid == 0) base_sh = 0;
-        __syncthreads();
-        for (int o0 = 0; o0 < n_ob; o0 += nt) {
-            const int o = o0 + tid;
+    for (int i = wave; i < n_t; i += nw) {
+        int base = 0;
+        for (int o0 = 0; o0 < n_ob; o0 += MP_WAVE) {
+            const int o = o0 + lane;
             const int q = o < n_st ? o : n_st + (o - n_st) * n_t + i;
             const bool hit = o < n_ob && flag[q];
             const unsigned long long bal = __ballot(hit);
-            if (lane == 0) wave_cnt[wave] = __popcll(bal);
-            __syncthreads();
-            int pos = base_sh;
-            for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
-            pos += __popcll(bal & ((1ull << lane) - 1ull));
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             if (hit) {
                 if (pos < a.r_max) {
                     a.s_down[((size_t)b * n_t + i) * a.r_max + pos] = res_dn[q];
                     a.s_up[((size_t)b * n_t + i) * a.r_max + pos] = res_u[q];
                 } else overflow = 1;
             }
-            __syncthreads();
-            if (tid == 0) {
-                int tot = 0;
-                for (int w = 0; w < nw; ++w) tot += wave_cnt[w];
-                base_sh += tot;
-            }
-            __syncthreads();
+            base += __popcll(bal);
         }
-        if (tid == 0) {
-            a.n_reg[(size_t)b * n_t + i] = min(base_sh, a.r_max);
-            if (i >= 1) regs_sum += min(base_sh, a.r_max);
-        }
-        __syncthreads();
+        if (lane == 0) a.n_reg[(size_t)b * n_t + i] = min(base, a.r_max);
+        if (i >= 1) regs_loc += min(base, a.r_max);
     }
+    if (lane == 0 && regs_loc) atomicAdd(&regs_sh, regs_loc);
     overflow = __syncthreads_or(overflow);
     if (tid == 0) {
         a.status[b] = overflow ? MP_ST_E_CAPACITY : MP_ST_OK;
-        if (a.key_out) a.key_out[b] = st_weight_bin(a.key_n_s[b], regs_sum, n_t);
+        if (a.key_out) a.key_out[b] = st_weight_bin(a.key_n_s[b], regs_sh, n_t);
     }
 }
 
