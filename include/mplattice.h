@@ -26,7 +26,9 @@
  * thread-per-node kernel), MP_SL_PAIR_CAP=n (size of the kernels' LDS pair
  * store), MP_ST_REGIONS_ONCE=0 (per-layer scans in mp_st_regions),
  * MP_ST_GENERIC=1 (mp_st_dp through the kernel that holds every relaxation path
- * instead of the instance built for the batch's interval bound r_max),
+ * instead of the instance built for the batch's interval bound r_max; =2: that
+ * kernel without its per-cell interval tables, so that every layer with intervals
+ * is relaxed by one thread per cell, the path grids too large for the tables take),
  * MP_ORDER=0 (the *_ordered entry points launch in the caller's order),
  * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n / MP_CV_THREADS=n (workgroup
  * size of mp_st_dp / mp_refline_tables / the front end / the two spline stages of

@@ -985,9 +985,6 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // n_s_max: the history word holds 8*(pp-2p) and 8*(3pp-ppp-3p) as signed 16-bit halves and
     // fire distances are u16 values of 16*d, so 24*n_s_max must stay below 32768 whatever LDS holds
     static_assert(24 * 1024 < 32768, "history word / fire distance encoding");
-    // n_s_max: the history word holds 8*(pp-2p) and 8*(3pp-ppp-3p) as signed 16-bit halves and
-    // fire distances are u16 values of 16*d, so 24*n_s_max must stay below 32768 whatever LDS holds
-    static_assert(24 * 1024 < 32768, "history word / fire distance encoding");
     if (n_t > 64 || n_s_max > 1024 || r_max > 256) {
         mp_set_error("mp_st_dp supports n_t <= 64, n_s_max <= 1024, r_max <= 256");
         return MP_E_UNSUPPORTED;
@@ -996,6 +993,7 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     int r_tab = r_max > 0 ? r_max : 1;
     if (r_tab > 8 || r_tab == 7) r_tab = 8; // the split path keeps a cell's intervals in registers (7 run as 8)
     while (r_tab > 0 && st_tab_bytes(n_s_max, r_tab) > 40 * 1024) --r_tab;
+    if (mp_knob_st_generic() == 2) r_tab = 0; // tests: no cell tables, every layer with intervals by a thread per cell
     StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, st_lanes_per_cell(B, n_s_max), n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
@@ -1014,13 +1012,11 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         mp_order_launch(B, order_ws, order_ws + B, st);
         a.order = order_ws + B;
     }
-    // batches with few intervals per layer (r_max is the caller's bound) take the instance
-    // built for that bound; MP_ST_GENERIC=1 keeps them on the kernel that holds every path
     // large batches with few intervals per layer (r_max is the caller's bound) take the
     // instance built for that bound and grid width class; MP_ST_GENERIC=1 keeps them on the
     // kernel that holds every path
     int rk = r_max == 7 ? 8 : r_max;
-    if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() != 1)) rk = -1;
+    if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() <= 0)) rk = -1;
 #define ST_R_LAUNCH(RT)                                                                      \
     if (a.lanes_per_cell == 4) hipLaunchKernelGGL((st_dp_r_kernel<RT, 4>), grid, block, lds, st, a); \
     else hipLaunchKernelGGL((st_dp_r_kernel<RT, 8>), grid, block, lds, st, a)

@@ -76,7 +76,8 @@ def test_all_65536_scenarios_two_independent_gpu_paths_agree(knob):
     """Every scenario of the configuration, not a sample: the fused SL kernel (pruned walk, runs
     of layers without exchange, pair store in LDS) against the materialised path (every edge of
     the lattice priced by the edge kernel into a tensor in HBM, then the plain DP over it), and
-    the lanes-per-cell ST DP against the thread-per-cell kernel.  Plans must agree bit for bit;
+    the lanes-per-cell ST DP (cell tables, walks split over four lanes) against the relaxation by
+    one thread per cell without tables (MP_ST_GENERIC=2).  Plans must agree bit for bit;
     the oracle pins both paths on samples elsewhere, this pins the rare scenario."""
     import torch
     import bench
@@ -94,7 +95,7 @@ def test_all_65536_scenarios_two_independent_gpu_paths_agree(knob):
         del edge
         st_in = (sc["st_n_s"], sc["down"], sc["up"], sc["n_reg"], sc["cur_vel"], bench.SPEED_LIM)
         st = mb.st_dp(*st_in, want_tables=False, n_s_max=bench.ST_N_S)
-        knob("MP_ST_GENERIC", 1)
+        knob("MP_ST_GENERIC", 2)
         st_plain = mb.st_dp(*st_in, want_tables=False, n_s_max=bench.ST_N_S)
         knob("MP_ST_GENERIC", -1)
         torch.cuda.synchronize()

@@ -452,3 +452,70 @@ def test_two_parts_on_two_streams_equal_the_single_call():
             assert torch.equal(got.isnan(), want.isnan()), k
             got, want = got.nan_to_num(), want.nan_to_num()
         assert torch.equal(got, want), k
+
+
+def test_full_size_batch_every_stage_against_an_independent_kernel(knob):
+    """All 4096 scenes of the benchmark's whole-replan workload, not a sample: what four stages
+    of the one-call chain left in the arena against kernels that reach the same results another
+    way, from the chain's own intermediates.  Obstacle frames to Frenet coordinates: the front
+    end's search through bounding boxes of sample blocks against mp_c2f_batch's walk over the
+    samples.  Path search: the lane-per-edge kernel against the fused kernel (thread per node,
+    pruned walk).  Blocked intervals: every scan once with a work list against a scan per time
+    layer.  Speed search: lanes per cell with cell tables against one thread per cell.  Bit for
+    bit; the oracle pins each of them on samples elsewhere."""
+    import types
+    import torch
+    import bench
+    from motion_planning_amd import batch as mb, pipeline as pl
+    B = 4096
+    sc = bench.make_scenes(B)
+    dev = {k: mb.to_dev(v, torch.int32 if v.dtype == np.int32 else torch.float64) for k, v in sc.items()}
+    dev["line_vec"] = torch.zeros(B, dtype=torch.float64, device="cuda")
+    params = pl.default_params()
+    dims = pl.plan_dims(B, sc["knots_x"].shape[1], 192, 64, n_l=5, m_max=200, params=params)
+    r = pl.plan_scenes(dev, dims, params).arrays
+    torch.cuda.synchronize()
+    status = r["status"]
+    live = (status == pl.PIPE_OK) | (status == pl.PIPE_NOT_FOUND)       # scenes the front end took
+    assert int(live.sum()) > B // 2
+    # 1. obstacle frames in Frenet coordinates
+    tabs = types.SimpleNamespace(m_max=dims.m_max, tab_x=r["tab_x"], tab_y=r["tab_y"], tab_s=r["tab_s"],
+                                 tab_theta=r["tab_theta"], tab_kappa=r["tab_kappa"], M=r["tab_m"])
+    scn = torch.arange(B, dtype=torch.int32, device="cuda")
+    s, l = mb.c2f(tabs, dev["st_pos"][..., 0], dev["st_pos"][..., 1], scn[:, None].expand(B, 192).contiguous())
+    assert torch.equal(s.reshape(B, 192)[live], r["st_s"][live]) and torch.equal(l.reshape(B, 192)[live], r["st_l"][live])
+    F = dims.n_frames
+    s, l = mb.c2f(tabs, dev["dy_pos"][..., 0], dev["dy_pos"][..., 1], scn[:, None, None].expand(B, 64, F).contiguous())
+    assert torch.equal(s.reshape(B, 64, F)[live], r["dy_s"][live]) and torch.equal(l.reshape(B, 64, F)[live], r["dy_l"][live])
+    # 2. path search on the chain's lattice and obstacle list
+    n_l = dims.n_l
+    sb = mb.SLBatch(r["s_layers"], r["l_row"][None].expand(B, n_l).contiguous(), r["ego_sl"], r["ob_s"], r["ob_l"],
+                    r["n_ob"], r["ob_dist"], n_layers=r["n_layers"], check=False)
+    knob("MP_SL_NARROW", 0)
+    fused = mb.sl_plan(sb, mb.sl_params(early_exit=True, n_l=n_l), want_maps=False)
+    knob("MP_SL_NARROW", -1)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.status[live], r["sl_status"][live])
+    assert torch.equal(fused.path_idx[live], r["path_idx"][live])
+    assert torch.equal(fused.layers_done[live], r["layers_done"][live])
+    assert np.array_equal(fused.best_cost[live].cpu().numpy(), r["best_cost"][live].cpu().numpy(), equal_nan=True)
+    # 3. blocked intervals from the chain's sampled path
+    ok = status == pl.PIPE_OK
+    n_t = dims.n_t
+    knob("MP_ST_REGIONS_ONCE", 0)
+    down, up, n_reg, reg_st = mb.st_regions(n_t, r["path_s"], r["path_l"], r["n_path"], r["st_s"], r["st_l"],
+                                            dev["st_rad"], dev["n_st"], r["dy_s"][:, :, :n_t].contiguous(),
+                                            r["dy_l"][:, :, :n_t].contiguous(), dev["dy_rad"], dev["n_dy"], dims.r_max)
+    knob("MP_ST_REGIONS_ONCE", -1)
+    torch.cuda.synchronize()
+    assert torch.equal(n_reg[ok], r["st_n_reg"][ok]) and torch.equal(reg_st[ok], r["reg_status"][ok])
+    used = torch.arange(dims.r_max, device="cuda")[None, None, :] < n_reg[:, :, None]
+    assert torch.equal((down * used)[ok], (r["st_down"] * used)[ok]) and torch.equal((up * used)[ok], (r["st_up"] * used)[ok])
+    # 4. speed search on the chain's intervals
+    knob("MP_ST_GENERIC", 2)
+    st = mb.st_dp(r["st_n_s"], r["st_down"], r["st_up"], r["st_n_reg"], r["robot_vel"], params.speed_lim,
+                  ds=params.st_ds, dt=params.st_dt, want_tables=False, n_s_max=dims.st_n_s_max)
+    knob("MP_ST_GENERIC", -1)
+    torch.cuda.synchronize()
+    assert torch.equal(st["path_len"][ok], r["st_path_len"][ok])
+    assert torch.equal(st["path_s_ind"][ok], r["st_path_s_ind"][ok])
