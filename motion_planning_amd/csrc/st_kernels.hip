@@ -41,6 +41,7 @@ extern "C" int mp_debug_st_counters(unsigned long long *out, int reset)
 struct StDev {
     int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
     int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
+    int32_t stage_all;                  // the intervals of every time layer sit in LDS from the start
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -166,6 +167,16 @@ struct StSh {
     __device__ __forceinline__ double &speed(int d) const { return fs[2 * d + 1]; }
 };
 
+// History word of cell j of layer i, whose predecessor bp has just been fixed, as the next
+// layer reads it when j is a predecessor there (see the LDS rows above): next to the cell's cost.
+__device__ __forceinline__ void st_store_hist(const StSh &sh, int i, int N, int j, int bp)
+{
+    const int lo = 8 * (bp - 2 * j);
+    int hi = lo; // layer 2 reads the acceleration offset twice (its jerk has no third predecessor)
+    if (i >= 2) hi = 8 * (3 * bp - (int)sh.pre16[(size_t)(i - 1) * N + bp] - 3 * j);
+    *(int *)(sh.ch_cur + 2 * j + 1) = (lo & 0xffff) | (hi << 16);
+}
+
 // All cells of time layer i >= 2 owned by this thread.
 //
 // Exact pruning: every term of the edge cost is non-negative and floating-point
@@ -213,6 +224,7 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
         }
         sh.cost_cur(j) = best;
         sh.pre16[(size_t)i * N + j] = (short)bp;
+        st_store_hist(sh, i, N, j, bp);
         if (cost_g) cost_g[(size_t)i * N + j] = best;
         if (pre_g) pre_g[(size_t)i * N + j] = bp;
         m_loc = best < m_loc ? best : m_loc;
@@ -274,7 +286,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     const int tid = threadIdx.x, nt = blockDim.x;
     const double ds = a.ds;
     const int n1 = n_s - 1;
-    // (every record's quiet word and flag word were reset before the barrier in front of this call)
+    // (every record's quiet word and flag word are at their reset values: set at the start of the
+    // plan and put back by whoever read them last, see below)
     const double front_step = sh.front(n_s > 1 ? 1 : 0);
     const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
     // q / n_s by multiplication: exact while q * n_s < 2^32 (q < 8 * n_s, n_s <= 1024); a
@@ -338,6 +351,9 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 #pragma unroll
             for (int k = 0; k < (RT + 1) / 2; ++k) fire[k] = ((const unsigned *)(rec + 2 * tb.r_tab + 1))[k];
             const int2 qf = *(const int2 *)(rec + 2 * tb.r_tab);
+            // (this lane group is the only reader of the cell's quiet and flag words in this layer:
+            // back to their reset values for the next layer's classification, behind a barrier)
+            if (RT > 0 && r == 0) *(int2 *)(rec + 2 * tb.r_tab) = make_int2(0x7fffffff, 0);
             const int e_quiet = RT > 0 ? qf.x : 0;
             const int e_brk = (RT == 0 || qf.y == 0) ? e_lim : 0x7fffffff;
             const double s = __dmul_rn((double)j, ds);
@@ -408,6 +424,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
         if (live && r == 0) {
             sh.cost_cur(j) = best;
             sh.pre16[(size_t)i * N + j] = (short)bp;
+            st_store_hist(sh, i, N, j, bp);
             if (cost_g) cost_g[(size_t)i * N + j] = best;
             if (pre_g) pre_g[(size_t)i * N + j] = bp;
             m_loc = best < m_loc ? best : m_loc;
@@ -446,14 +463,18 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     sh.acc = sh.ch_cur + 2 * N;    // index n + (n_s-1), n in [-(n_s-1), n_s-1]
     sh.jerk2 = sh.acc + 2 * N;     // same index, layer i == 2
     sh.jerk3 = sh.jerk2 + 2 * N;   // index m + 2(n_s-1), layers i >= 3
-    sh.down = sh.jerk3 + 4 * N;
-    sh.up = sh.down + R_max;
-    double *last_col = sh.up + R_max;
+    // blocked intervals: one layer's (staged layer by layer) or, when they are few, every layer's
+    const bool stage_all = a.stage_all != 0;
+    const int R_slots = stage_all ? R_max * n_t : R_max;
+    double *down_all = sh.jerk3 + 4 * N, *up_all = down_all + R_slots;
+    sh.down = down_all;
+    sh.up = up_all;
+    double *last_col = up_all + R_slots;
     double *red = last_col + n_t;
     sh.pre16 = (short *)(red + 8);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
     StTab tb; // placed by offset from smem so the pointers stay LDS pointers
-    tb.rec = smem + st_tab_offset(N, R_max, n_t) / 8;
+    tb.rec = smem + st_tab_offset(N, R_slots, n_t) / 8;
     tb.r_tab = a.r_tab;
     tb.stride = st_rec_stride(a.r_tab);
 
@@ -501,49 +522,57 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         if (pre_g) pre_g[j] = -1;
     }
     if (tid == 0) last_col[0] = 0.0;
+    // quiet and flag word of every cell record at their reset values (whoever reads them puts them back)
+    for (int j = tid; j < n_s; j += nt) {
+        tb.quiet(j)[0] = 0x7fffffff;
+        tb.quiet(j)[1] = 0;
+    }
+    if (stage_all) {
+        for (int q = tid; q < (n_t - 1) * R_max; q += nt) {
+            const int i = 1 + q / R_max, k = q - (i - 1) * R_max;
+            if (k < min(max(a.n_reg[(size_t)b * n_t + i], 0), R_max)) {
+                down_all[i * R_max + k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
+                up_all[i * R_max + k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
+            }
+        }
+    }
     __syncthreads();
     const int d_lim = *d_lim_sh;
     double m_prev = 0.0; // minimum of cost_prev
 
-    // the blocked intervals of a layer are fetched from global memory while the layer
-    // before it is relaxed (one interval per thread; any beyond blockDim are read directly)
+    // the interval count of a layer is fetched while the layer before it is relaxed; so are the
+    // intervals themselves when they are staged layer by layer (one per thread; any beyond
+    // blockDim are read directly)
     int R_next = min(max(a.n_reg[(size_t)b * n_t + 1], 0), R_max);
     double pf_down = 0.0, pf_up = 0.0;
-    if (tid < R_next) {
+    if (!stage_all && tid < R_next) {
         pf_down = a.s_down[((size_t)b * n_t + 1) * R_max + tid];
         pf_up = a.s_up[((size_t)b * n_t + 1) * R_max + tid];
     }
     for (int i = 1; i < n_t; ++i) {
         const int R = R_next;
-        if (tid < R) {
-            sh.down[tid] = pf_down;
-            sh.up[tid] = pf_up;
-        }
-        for (int k = tid + nt; k < R; k += nt) {
-            sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
-            sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
-        }
-        for (int j = tid; j < n_s; j += nt) {
-            tb.quiet(j)[0] = 0x7fffffff;
-            tb.quiet(j)[1] = 0;
-        }
-        if (i >= 2) {
-            // the predecessor chain of every cell of the layer below (final since the last barrier)
-            for (int p = tid; p < n_s; p += nt) {
-                const int pp = sh.pre16[(size_t)(i - 1) * N + p];
-                const int ppp = sh.pre16[(size_t)(i - 2) * N + pp];
-                const int lo = 8 * (pp - 2 * p);
-                sh.hist_prev(p) = (lo & 0xffff) | ((i == 2 ? lo : 8 * (3 * pp - ppp - 3 * p)) << 16);
+        if (stage_all) {
+            sh.down = down_all + i * R_max;
+            sh.up = up_all + i * R_max;
+        } else {
+            // (the layer before this one has finished with the staging row: the barrier at its end)
+            if (tid < R) {
+                sh.down[tid] = pf_down;
+                sh.up[tid] = pf_up;
+            }
+            for (int k = tid + nt; k < R; k += nt) {
+                sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
+                sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
             }
         }
         if (i + 1 < n_t) {
             R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
-            if (tid < R_next) {
+            if (!stage_all && tid < R_next) {
                 pf_down = a.s_down[((size_t)b * n_t + i + 1) * R_max + tid];
                 pf_up = a.s_up[((size_t)b * n_t + i + 1) * R_max + tid];
             }
         }
-        __syncthreads();
+        if (!stage_all) __syncthreads();
         double m_loc = MP_INF;
         if (i == 1) {
             // only p_j = 0 (speed_planner.py:96-100)
@@ -559,6 +588,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                                         __dmul_rn(__dmul_rn(jk, jk), dt));
                 sh.cost_cur(j) = best;
                 sh.pre16[(size_t)i * N + j] = 0;
+                st_store_hist(sh, i, N, j, 0);
                 if (cost_g) cost_g[(size_t)i * N + j] = best;
                 if (pre_g) pre_g[(size_t)i * N + j] = 0;
                 m_loc = best < m_loc ? best : m_loc;
@@ -994,14 +1024,18 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     if (r_tab > 8 || r_tab == 7) r_tab = 8; // the split path keeps a cell's intervals in registers (7 run as 8)
     while (r_tab > 0 && st_tab_bytes(n_s_max, r_tab) > 40 * 1024) --r_tab;
     if (mp_knob_st_generic() == 2) r_tab = 0; // tests: no cell tables, every layer with intervals by a thread per cell
-    StDev a{n_t, n_s_max, r_max > 0 ? r_max : 1, r_tab, st_lanes_per_cell(B, n_s_max), n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    // the intervals of every layer in LDS from the start when that is a few kilobytes: a layer
+    // then begins without a barrier
+    const int r_slots_1 = r_max > 0 ? r_max : 1;
+    const int stage_all = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024;
+    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), stage_all, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_tab_offset(n_s_max, a.r_max, n_t) + st_tab_bytes(n_s_max, r_tab);
+    size_t lds = st_tab_offset(n_s_max, stage_all ? a.r_max * n_t : a.r_max, n_t) + st_tab_bytes(n_s_max, r_tab);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
