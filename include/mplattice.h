@@ -358,7 +358,9 @@ int mp_pack_results(int32_t B, int32_t n_s, int32_t n_t, const int32_t *path_idx
 #define MP_PLAN_NOT_FOUND 0        /* PathPlanner.plan returned (False, [])           */
 #define MP_PLAN_E_EMPTY_EDGE (-2)  /* = MP_SL_E_EMPTY_EDGE                            */
 #define MP_PLAN_E_CAPACITY (-3)    /* = MP_SL_E_CAPACITY, or more layers than n_s_max */
-#define MP_PLAN_E_MAP_TOO_BIG (-4) /* sl_map.py:57-60 ValueError                      */
+#define MP_PLAN_E_MAP_TOO_BIG (-4) /* sl_map.py:57-60 ValueError; also a line whose samples
+                                      exceed m_max while its knots span more than the map
+                                      may be long (its arc length is at least that span)  */
 #define MP_PLAN_E_BAD_LINE (-5)    /* reference-line tables failed (MP_RL_E_*)        */
 #define MP_PLAN_E_ST_CAPACITY (-6) /* ST grid wider than st_n_s_max, more blocked
                                       intervals than r_max, path longer than p_max or

@@ -280,9 +280,19 @@ __global__ void plan_frontend_kernel(FrontDev a)
     const double end_s = a.o.origin[4 * b + 2];
     // (world-frame call: a scene that kept more obstacles than its slots hold is not planned)
     const bool crowded = a.o.w_status && a.o.w_status[b] != 0;
+    // A line with more samples than the tables hold whose knots alone span more than the map
+    // may be long: the reference builds its converter and then raises "map too big" for it
+    // (sl_map.py:57-60; the arc length is at least the span), so that is the scene's outcome,
+    // whatever m_max the caller chose.
+    bool too_long = false;
+    if (!line_ok && a.o.rl_status[b] == MP_RL_E_CAPACITY) {
+        const int nk = a.in.n_knots[b];
+        const double *kx = a.in.knots_x + (size_t)b * d.n_knots_max;
+        too_long = nk >= 2 && nk <= d.n_knots_max && kx[nk - 1] - kx[0] > a.max_map_len;
+    }
     if (!line_ok || end_s > a.max_map_len || crowded) {
         if (tid == 0) {
-            a.o.status[b] = !line_ok ? MP_PLAN_E_BAD_LINE
+            a.o.status[b] = too_long ? MP_PLAN_E_MAP_TOO_BIG : !line_ok ? MP_PLAN_E_BAD_LINE
                                      : (end_s > a.max_map_len ? MP_PLAN_E_MAP_TOO_BIG : MP_PLAN_E_CAPACITY);
             a.o.n_layers[b] = 0;
             a.o.n_ob[b] = 0;

@@ -93,6 +93,9 @@ class PlanArena:
             self.arrays[name.value.decode()] = self.base[off.value:off.value + nb].view(dt).view(shp)
 
 
+M_MAX_MAP = 232   # reference-line samples every 0.5 m for a 100 m map, with a margin
+
+
 def plan_dims(B, n_knots_max, n_st_max, n_dy_max, n_l=5, m_max=232, plan_time=5, params=None, want_maps=False,
               n_frames=N_FRAMES, r_max=None, world=False):
     """Arena sizes for scenes of the given shape: capacities follow from the map length
@@ -198,8 +201,8 @@ def plan_batch(knots_x, knots_y, n_knots, ego_vel, st_pos, st_rad, n_st, dy_pos,
     dy_rad [B, Nd], n_dy [B].  path_planner "dp" runs the SL lattice DP (PathPlanner),
     "track" follows the lattice's centre lane (TrackPathPlanner, the planner the
     reference's PlannerInterface.path_plan instantiates, planner_interface.py:133-138).
-    m_max: reference-line samples per scene (default: from the knots' x span, which
-    costs one device->host read when the knots are device tensors).
+    m_max: reference-line samples per scene (default: from the knots' x span; for knots
+    already on the device the samples of the longest line a map may hold, no read back).
     Returns a dict of tensors indexed by scene; `status` [B] is PIPE_OK,
     PIPE_NOT_FOUND or a negative PIPE_* code; the dict also carries `arena`
     (reusable through the `arena` argument for batches of the same shape)."""
@@ -208,9 +211,14 @@ def plan_batch(knots_x, knots_y, n_knots, ego_vel, st_pos, st_rad, n_st, dy_pos,
     dev = mb._dev()
     f64 = dict(dtype=torch.float64, device=dev)
     if m_max is None:
-        kx = knots_x if isinstance(knots_x, torch.Tensor) else torch.as_tensor(np.asarray(knots_x))
-        span = float((kx.max(dim=1).values - kx.min(dim=1).values).max()) if kx.numel() else 0.0
-        m_max = int(span / 0.5) + 8
+        if isinstance(knots_x, torch.Tensor) and knots_x.is_cuda:
+            # no device->host read: samples for the longest line a map may hold (100 m) and a
+            # margin; a longer line is reported as PIPE_MAP_TOO_BIG, as the reference raises
+            m_max = M_MAX_MAP
+        else:
+            kx = torch.as_tensor(np.asarray(knots_x))
+            span = float((kx.max(dim=1).values - kx.min(dim=1).values).max()) if kx.numel() else 0.0
+            m_max = int(span / 0.5) + 8
     knots_x, knots_y = mb.to_dev(knots_x), mb.to_dev(knots_y)
     B = knots_x.shape[0]
 

@@ -233,6 +233,18 @@ def test_pipeline_map_too_big_is_a_status():
     r = pl.plan_batch(**pack_scenes([ok, big]))
     torch.cuda.synchronize()
     assert list(r["status"].cpu().numpy()) == [pl.PIPE_OK, pl.PIPE_MAP_TOO_BIG]
+    # knots already on the device: no read back to size the tables, which then hold the samples
+    # of a 100 m map; a line with more samples than that (here 128 m, and one of 300 m) is the
+    # same "map too big", not a table error
+    from motion_planning_amd import batch as mb
+    huge = dict(ok, rx=-2.0 + 10.0 * np.arange(31), ry=np.zeros(31))
+    packed = pack_scenes([ok, big, huge])
+    for k in ("knots_x", "knots_y"):
+        packed[k] = mb.to_dev(packed[k])
+    r = pl.plan_batch(**packed)
+    torch.cuda.synchronize()
+    assert r["dims"].m_max == pl.M_MAX_MAP
+    assert list(r["status"].cpu().numpy()) == [pl.PIPE_OK, pl.PIPE_MAP_TOO_BIG, pl.PIPE_MAP_TOO_BIG]
 
 
 def test_unsampled_result_is_not_reported_as_planned():
