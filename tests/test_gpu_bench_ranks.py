@@ -52,3 +52,22 @@ def test_two_ranks_split_the_65536_scenarios():
     assert d["config"]["total_scenarios"] == 65536 and d["config"]["shards"] == [32768, 32768]
     assert d["config"]["per_gpu_batch"] == 32768 and d["scenarios_rank0"] == 32768
     assert d["value"] > 0 and d["value_no_exchange"] > 0 and d["job"]["world_size"] == 2
+
+
+def test_one_rank_exchange_over_rccl():
+    """The exchange as the multi-GPU run issues it (device-side record packing, asynchronous
+    all_gather_into_tensor on device tensors through the "nccl" backend, which is RCCL here), with
+    a group of one rank: MP_BENCH_FORCE_DIST=1 switches it on for a single process."""
+    env = dict(os.environ, MP_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MP_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scenarios", "512", "--steps", "2",
+           "--reps", "2", "--warmup", "1", "--cpu-sample", "0", "--materialised", "0", "--h2d-reps", "1",
+           "--pipeline-steps", "2", "--pipeline-scenes", "256", "--single-plan", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl"
+    assert d["job"]["backend"] == "nccl" and "RCCL" in d["job"]["collective_library"]
+    assert d["value"] > 0 and d["value_no_exchange"] > 0 and d["exchange_overhead_frac"] < 1.0
+    assert d["value_end_to_end"] > 0 and d["pipeline"]["value"] > 0
