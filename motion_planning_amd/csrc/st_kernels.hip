@@ -143,7 +143,9 @@ struct StCellLds {
 // (cost, history word).  The history word of predecessor p of the current layer packs
 // 8*(pp - 2p) in the low half and 8*(3pp - ppp - 3p) in the high half (on layer 2, whose
 // jerk has no third predecessor, 8*(pp - 2p) again): byte offsets into the acceleration
-// and jerk tables, looked up once per layer instead of two dependent reads per edge.
+// and jerk tables, written once per cell when its predecessor is fixed (st_store_hist)
+// instead of two dependent reads per edge.
+//
 // Lanes per cell of the split relaxation.  Pruning makes the walks short, so in a large
 // batch (throughput) the cost of a pass over the cells counts as much as the balance of the
 // lanes: grids of up to 128 cells give a cell 4 lanes (two passes of 64 cells instead of four
@@ -162,7 +164,6 @@ struct StSh {
     short *pre16;
     __device__ __forceinline__ double &cost_prev(int p) const { return ch_prev[2 * p]; }
     __device__ __forceinline__ double &cost_cur(int j) const { return ch_cur[2 * j]; }
-    __device__ __forceinline__ int &hist_prev(int p) const { return *(int *)(ch_prev + 2 * p + 1); }
     __device__ __forceinline__ double &front(int d) const { return fs[2 * d]; }
     __device__ __forceinline__ double &speed(int d) const { return fs[2 * d + 1]; }
 };
