@@ -803,3 +803,68 @@ def test_sl_few_pairs_in_long_runs_of_layers_without_exchange(oracle, knob, n_ob
                    index_map=full.index_map[b].cpu().numpy(), path_idx=full.path_idx[b].cpu().numpy(),
                    layers_done=int(full.layers_done[b]))
         assert_sl_parity(got, ref)
+
+
+FUZZ_SHAPES = [
+    # B, n_s, n_l, gap, n_ob_max, r_lo, r_hi
+    (1024, 64, 128, 1.5, 50, 0.3, 0.8),     # the benchmark's lattice with 0..50 obstacles
+    (1024, 64, 128, 1.5, 8, 0.3, 0.9),      # sparse: runs of layers with fewer pairs than layers
+    (2048, 40, 64, 2.0, 30, 0.2, 0.9),
+    (2048, 20, 33, 3.0, 60, 0.2, 0.7),
+    (2048, 64, 17, 1.5, 120, 0.3, 0.8),     # one wave of 17 lanes, crowded
+    (4096, 12, 16, 8.0, 100, 0.3, 0.9),     # lane-per-edge kernel, full groups
+    (4096, 12, 5, 8.0, 40, 0.3, 0.9),       # the default lattice
+    (512, 10, 200, 1.5, 30, 0.1, 0.4),      # four waves per scenario
+]
+
+
+@pytest.mark.parametrize("shape", FUZZ_SHAPES, ids=lambda s: "B%d_%dx%d_ob%d" % (s[0], s[1], s[2], s[4]))
+def test_sl_many_random_scenarios_fused_against_materialised(knob, shape):
+    """Thousands of random scenarios per lattice shape (obstacle counts 0..max, layer counts that
+    differ per scenario, both exit modes, the pair store at its own size and forced to refill):
+    every fused instance against the materialised path (edge tensor + plain DP), bit for bit.
+    The oracle pins both on small batches above; this looks for the scenario in ten thousand."""
+    import torch
+    from motion_planning_amd import batch as mb
+    B, n_s, n_l, gap, n_ob_max, r_lo, r_hi = shape
+    rng = np.random.default_rng(77 + n_s * n_l + n_ob_max)
+    s_layers = np.cumsum(np.full((B, n_s), gap), axis=1)
+    s_layers[:, -1] += rng.uniform(-0.4 * gap, 0.9 * gap, B)
+    l_row = np.broadcast_to(np.linspace(-1.45, 1.45, n_l), (B, n_l)).copy()
+    ego = np.stack([np.zeros(B), rng.uniform(-0.3, 0.3, B)], 1)
+    ob_s = rng.uniform(0.5, s_layers[0, -1], (B, n_ob_max))
+    ob_l = rng.uniform(-2.5, 2.5, (B, n_ob_max))
+    n_ob = rng.integers(0, n_ob_max + 1, B).astype(np.int32)
+    ob_dist = rng.uniform(r_lo, r_hi, B)
+    n_layers = np.where(rng.random(B) < 0.25, rng.integers(1, n_s + 1, B), n_s).astype(np.int32)
+    sb = mb.SLBatch(s_layers, l_row, ego, ob_s, ob_l, n_ob, ob_dist, n_layers=n_layers)
+    n_found = 0
+    for early_exit in (True, False):
+        prm = mb.sl_params(early_exit=early_exit, n_l=n_l)
+        edge, est = mb.sl_edge_cost(sb, prm)
+        plain = mb.sl_dp(edge, prm, n_layers=n_layers)
+        del edge
+        torch.cuda.synchronize()
+        assert bool((est == 1).all())
+        for cap in (None, 32):
+            if cap is not None:
+                knob("MP_SL_PAIR_CAP", cap)
+            outs = [mb.sl_plan(sb, prm, want_maps=True), mb.sl_plan(sb, prm, want_maps=False),
+                    mb.sl_plan(sb, prm, want_maps=False, ordered=False)]
+            if n_l <= 16:
+                knob("MP_SL_NARROW", 0)     # the same lattice through the thread-per-node kernel
+                outs.append(mb.sl_plan(sb, prm, want_maps=True))
+                knob("MP_SL_NARROW", -1)
+            knob("MP_SL_PAIR_CAP", -1)
+            torch.cuda.synchronize()
+            for o in outs:
+                bad = ((o.path_idx != plain.path_idx).any(1) | (o.status != plain.status) |
+                       (o.layers_done != plain.layers_done)).nonzero().flatten()
+                assert bad.numel() == 0, "scenarios %s differ (early_exit %s, cap %s)" % (
+                    bad[:8].cpu().numpy(), early_exit, cap)
+                assert np.array_equal(o.best_cost.cpu().numpy(), plain.best_cost.cpu().numpy(), equal_nan=True)
+                if o.cost_map is not None:
+                    assert torch.equal(o.cost_map, plain.cost_map) and torch.equal(o.index_map, plain.index_map)
+        assert bool(((plain.status == 0) | (plain.status == 1)).all())
+        n_found += int((plain.status == 1).sum())
+    print("found %d of %d plans" % (n_found, 2 * B))

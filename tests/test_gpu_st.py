@@ -398,3 +398,50 @@ def test_st_regions_random_vs_oracle(oracle, sizes, once, knob):
         for i in range(n_t):
             assert np.array_equal(down[b, i, :rn[i]].cpu().numpy(), rd[i, :rn[i]])
             assert np.array_equal(up[b, i, :rn[i]].cpu().numpy(), ru[i, :rn[i]])
+
+
+@pytest.mark.parametrize("n_s_hi,r_max,B", [(97, 5, 8192), (101, 8, 4096), (60, 3, 8192), (128, 2, 4096),
+                                             (200, 6, 1024), (33, 12, 4096)])
+def test_st_many_random_scenarios_every_relaxation_agrees(knob, n_s_hi, r_max, B):
+    """Thousands of random ST grids per shape (widths 2..n_s_hi, 0..r_max intervals per layer,
+    some with their end before their start, intervals sitting exactly on grid values): the
+    instance built for the interval bound, the kernel that holds every path (with and without
+    the cost / predecessor tables written), both lane splits and the relaxation by one thread
+    per cell give the same plans, and the same tables where they are written, bit for bit."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(500 + n_s_hi + r_max)
+    n_t = 11
+    n_s = rng.integers(2, n_s_hi + 1, B).astype(np.int32)
+    n_s[: B // 4] = n_s_hi
+    down = rng.uniform(-5.0, n_s_hi + 10.0, (B, n_t, max(r_max, 1)))
+    snap = rng.random(down.shape) < 0.2
+    down[snap] = np.round(down[snap])                       # on grid values
+    up = down + rng.uniform(0.0, 6.0, down.shape)
+    flip = rng.random(down.shape) < 0.03
+    up[flip] = down[flip] - rng.uniform(0.0, 2.0, int(flip.sum()))   # an end before its start
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    n_reg[rng.random(B) < 0.3] = 0
+    cur = rng.uniform(0.0, 12.0, B)
+    args = (mb.to_dev(n_s, torch.int32), mb.to_dev(down), mb.to_dev(up), mb.to_dev(n_reg, torch.int32), mb.to_dev(cur))
+    ref = mb.st_dp(*args, LIM, want_tables=True, n_s_max=n_s_hi)
+    outs = {"instance / library's choice": mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)}
+    for lanes in (4, 8):
+        knob("MP_ST_LANES", lanes)
+        outs["%d lanes per cell" % lanes] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
+        knob("MP_ST_GENERIC", 1)
+        outs["every path, %d lanes" % lanes] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
+        outs["every path, tables, %d lanes" % lanes] = mb.st_dp(*args, LIM, want_tables=True, n_s_max=n_s_hi)
+        knob("MP_ST_GENERIC", -1)
+    knob("MP_ST_LANES", -1)
+    knob("MP_ST_GENERIC", 2)
+    outs["thread per cell"] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
+    outs["thread per cell, tables"] = mb.st_dp(*args, LIM, want_tables=True, n_s_max=n_s_hi)
+    knob("MP_ST_GENERIC", -1)
+    torch.cuda.synchronize()
+    assert int(ref["path_len"].min()) >= 2
+    for name, o in outs.items():
+        bad = ((o["path_s_ind"] != ref["path_s_ind"]).any(1) | (o["path_len"] != ref["path_len"])).nonzero().flatten()
+        assert bad.numel() == 0, "%s: plans of scenarios %s differ" % (name, bad[:8].cpu().numpy())
+        if o.get("cost") is not None:
+            assert torch.equal(o["cost"], ref["cost"]) and torch.equal(o["pre"], ref["pre"]), name
