@@ -291,3 +291,47 @@ def test_curve_eval_irregular_walks_vs_oracle(oracle):
             close(r["x"][b, :len(tt)].cpu().numpy(), want[0], rtol=1e-10)
             close(r["dx"][b, :len(tt)].cpu().numpy(), want[1], rtol=1e-10)
     assert n_err >= 1
+
+
+def test_refline_tables_same_bits_for_every_workgroup_size(knob):
+    """A large batch builds a line's tables with one wave per line, a small one with two or four
+    waves; lines of 3..24 knots with regular, short and long segments (the sequential segment walk
+    and the lagged one), ragged knot counts and different origins: every table, the origin and
+    the Frenet->Cartesian table come out with the same bits whatever the workgroup size."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(21)
+    B, nk_max = 2048, 24
+    kx = np.zeros((B, nk_max))
+    ky = np.zeros((B, nk_max))
+    nk = rng.integers(3, nk_max + 1, B).astype(np.int32)
+    for b in range(B):
+        kind = b % 4
+        gaps = (np.full(nk_max, 4.5) if kind == 0 else rng.uniform(0.2, 6.0, nk_max) if kind == 1
+                else rng.uniform(6.0, 12.0, nk_max) if kind == 2 else rng.uniform(3.0, 5.0, nk_max))
+        xs = -2.0 + np.concatenate([[0.0], np.cumsum(gaps[: nk_max - 1])])
+        kx[b] = xs
+        ky[b] = rng.uniform(-0.006, 0.006) * xs * xs + 0.3 * np.sin(xs / rng.uniform(6.0, 15.0))
+    ego = rng.uniform(-1.0, 6.0, (B, 2))
+    ego[:, 1] = rng.uniform(-0.5, 0.5, B)
+    outs = {}
+    for threads in (-1, 64, 128, 256):
+        knob("MP_RL_THREADS", threads)
+        outs[threads] = mb.refline_tables(kx, ky, nk, np.zeros(B), ego, m_max=600)
+    knob("MP_RL_THREADS", -1)
+    small = mb.refline_tables(kx[:7], ky[:7], nk[:7], np.zeros(7), ego[:7], m_max=600)   # library's choice for a small batch
+    torch.cuda.synchronize()
+    ref = outs[256]
+    assert int((ref.status == 1).sum()) > B // 2
+    fields = ("tab_x", "tab_y", "tab_s", "tab_theta", "tab_kappa", "M", "origin", "status", "inv_x", "inv_s", "inv_y",
+              "inv_theta", "n_inv")
+    ok = ref.status == 1
+    for threads, t in outs.items():
+        assert torch.equal(t.status, ref.status) and torch.equal(t.M, ref.M), threads
+        for f in fields:
+            a, r = getattr(t, f), getattr(ref, f)
+            assert torch.equal(torch.nan_to_num(a[ok]), torch.nan_to_num(r[ok])), (threads, f)
+    for f in fields:
+        a, r = getattr(small, f), getattr(ref, f)[:7]
+        k = ok[:7]
+        assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(r[k])), ("small batch", f)

@@ -531,3 +531,15 @@ def test_full_size_batch_every_stage_against_an_independent_kernel(knob):
     torch.cuda.synchronize()
     assert torch.equal(st["path_len"][ok], r["st_path_len"][ok])
     assert torch.equal(st["path_s_ind"][ok], r["st_path_s_ind"][ok])
+    # 5. the stages that size their workgroup by the batch (one wave per scene in a large batch):
+    # the same bits with the workgroups a small batch gets
+    keep = {k: r[k].clone() for k in ("status", "tab_s", "tab_theta", "path_s", "path_l", "n_path", "st_n_s", "ss", "vv",
+                                      "final_x", "final_y", "n_prof")}
+    knob("MP_RL_THREADS", 256)
+    knob("MP_CV_THREADS", 128)
+    r2 = pl.plan_scenes(dev, dims, params).arrays
+    knob("MP_RL_THREADS", -1)
+    knob("MP_CV_THREADS", -1)
+    torch.cuda.synchronize()
+    for k, v in keep.items():
+        assert torch.equal(torch.nan_to_num(r2[k]), torch.nan_to_num(v)), k
