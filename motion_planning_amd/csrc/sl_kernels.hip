@@ -194,14 +194,16 @@ struct Collider {
     LayerGeom g;
     double p1s, p2s, d_s, r2;
     int n_ent, n_ob;
-    mutable int last; // NE == -1: the pair that hit last time (-1: none yet), tried first the next time
+    // NE == -1: the pair that hit last time (-1: none yet), tried first the next time; one per
+    // side of the walk, whose two sides are usually blocked by different pairs
+    mutable int last[2];
     __device__ __forceinline__ void init(const double *eh, const double *eo, const double *ed, int ne,
                                          const LayerGeom &g_, double p1s_, double p2s_, double d_s_,
                                          const double *obs, const double *obl, int nob, double r2_)
     {
         e_h0 = eh; e_ol = eo; e_ds2 = ed; n_ent = ne;
         g = g_; p1s = p1s_; p2s = p2s_; d_s = d_s_; ob_s = obs; ob_l = obl; n_ob = nob; r2 = r2_;
-        last = -1;
+        last[0] = last[1] = -1;
         if constexpr (NE > 0) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
@@ -212,7 +214,7 @@ struct Collider {
             }
         }
     }
-    __device__ __forceinline__ bool hit(double l1, double dl) const
+    __device__ __forceinline__ bool hit(double l1, double dl, int side = 0) const
     {
         bool h = false;
         if constexpr (NE > 0) {
@@ -221,7 +223,8 @@ struct Collider {
         } else if constexpr (NE == -1) {
             // A walk along a blocked stretch of sources meets the same obstacle edge after edge:
             // the pair that hit last time is tried first, and only a miss looks at the list.
-            if (last >= 0 && pair_hit(l1, dl, e_h0[last], e_ol[last], e_ds2[last], r2)) return true;
+            const int lst = last[side];
+            if (lst >= 0 && pair_hit(l1, dl, e_h0[lst], e_ol[lst], e_ds2[lst], r2)) return true;
             // in blocks of 8, so that a wave whose edges have all hit something stops early
             // (crowded layers have hundreds of pairs)
             for (int e0 = 0; e0 < n_ent && !h; e0 += 8) {
@@ -229,7 +232,7 @@ struct Collider {
                 for (int e = e0; e < e1; ++e)
                     if (pair_hit(l1, dl, e_h0[e], e_ol[e], e_ds2[e], r2)) {
                         h = true;
-                        last = e;
+                        last[side] = e;
                     }
             }
         } else if constexpr (NE == -2) {
@@ -531,14 +534,14 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
     // BOUND_FIRST (layers with many pairs): a candidate is first priced without the obstacle
     // penalty (a lower bound of its cost, since the penalty only adds and rounding is
     // monotone) and its pairs are only looked at if that bound could still win.
-    auto consider = [&](int j, double l1, double cp, double dl) {
+    auto consider = [&](int j, double l1, double cp, double dl, int side) {
         bool hit = false;
         if constexpr (!BOUND_FIRST) {
             // the collision test first: a candidate that hits pays the penalty, and where its
             // own cost plus the penalty already leaves no room (a blocked target walking along
             // a blocked stretch of sources) the closed form is not needed
             if constexpr (COUNT) ++*n_test;
-            hit = col.hit(l1, dl);
+            hit = col.hit(l1, dl, side);
             if (hit && w_inv > 0.0) {
                 double gap = (best - cp) - pen * (1.0 - 1e-12);
                 gap = (gap > 0.0 ? gap : 0.0) + 1e-12 * (g_max + fabs(best));
@@ -552,7 +555,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
         if constexpr (BOUND_FIRST) {
             c = e + cp;
             if (!(c < best || (c == best && j < bj))) return; // lower index wins ties
-            if (col.hit(l1, dl)) c = (e + pen) + cp;
+            if (col.hit(l1, dl, side)) c = (e + pen) + cp;
         } else {
             c = (e + (hit ? pen : 0.0)) + cp;
         }
@@ -582,7 +585,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 jd = (sorted && dl > 0.0) ? -1 : jd - 1; // sorted: sources further down are further away
             } else {
-                if (!cannot_win(dl * dl, lc.y)) consider(jd, lc.x, lc.y, dl);
+                if (!cannot_win(dl * dl, lc.y)) consider(jd, lc.x, lc.y, dl, 0);
                 --jd;
             }
         }
@@ -592,7 +595,7 @@ __device__ __forceinline__ double relax_target(int n_src, const SrcSh &src, doub
             if (dl * dl > w2) {
                 ju = (sorted && dl < 0.0) ? n_src : ju + 1;
             } else {
-                if (!cannot_win(dl * dl, lc.y)) consider(ju, lc.x, lc.y, dl);
+                if (!cannot_win(dl * dl, lc.y)) consider(ju, lc.x, lc.y, dl, 1);
                 ++ju;
             }
         }
