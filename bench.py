@@ -1254,7 +1254,7 @@ def bench_lattice(args, job):
     st_issue = issue_of("st_dp_kernel", st_ms)
     st_name = ("st_dp_r_kernel<%d,4> (speed DP over the ST grid: the instance of st_dp_kernel for at most %d blocked "
                "intervals per layer, 4 lanes per cell)" % (ST_R, ST_R)) if B >= 2048 else \
-        "st_dp_kernel<false> (speed DP over the ST grid)"
+        "st_dp_plain_kernel (speed DP over the ST grid: the kernel that holds every relaxation path)"
     roof_st = {"bound": "valu", "kernel": st_name,
                "achieved": st_tf, "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s", "frac": st_tf / VALU_FP64_PEAK_TF,
                "traffic": traffic_of("st_dp_kernel"), "kernel_ms": st_ms,

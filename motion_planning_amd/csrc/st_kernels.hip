@@ -41,7 +41,7 @@ extern "C" int mp_debug_st_counters(unsigned long long *out, int reset)
 struct StDev {
     int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
     int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
-    int32_t stage_all;                  // the intervals of every time layer sit in LDS from the start
+    int32_t r_pitch;                    // interval slots per time layer in LDS (layers with more are read from global memory)
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -189,8 +189,11 @@ __device__ __forceinline__ void st_store_hist(const StSh &sh, int i, int N, int 
 // stops once (ob(d) + speed[d]) + min(cost_prev) exceeds it.  Skipped
 // predecessors are strictly worse, so cost, first-minimum index and every tie
 // are exactly those of the full scan.
+// down / up: the layer's intervals, in LDS or (a layer with more intervals than LDS has slots
+// for) in global memory; every call site passes one kind, so the loads are typed.
 template <class CELL>
-__device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh, int i, int n_s, int N, int R,
+__device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh, const double *down,
+                                                 const double *up, int i, int n_s, int N, int R,
                                                  int d_lim, double m_prev, double *cost_g, int32_t *pre_g)
 {
     const double ds = a.ds;
@@ -200,7 +203,7 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
     for (int j = threadIdx.x; j < n_s; j += blockDim.x) {
         const double s = __dmul_rn((double)j, ds);
         CELL cell;
-        cell.init(s, sh.down, sh.up, R);
+        cell.init(s, down, up, R);
         double best = MP_INF;
         int bp = -1;
         for (int p = j; p >= 0; --p) {
@@ -250,7 +253,7 @@ __host__ __device__ __forceinline__ int st_rec_stride(int r_tab) { return r_tab 
 // Bytes of dynamic LDS in front of the cell records (see st_dp_kernel).
 __host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t)
 {
-    size_t b = ((size_t)14 * N + 2 * r_max + n_t + 8) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
+    size_t b = ((size_t)14 * N + 2 * r_max + n_t + 16) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
                2 * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -436,7 +439,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 
 // One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
 //   fs[N][2] row0[N][2] row1[N][2] acc[2N] jerk2[2N] jerk3[4N]
-//   down[r_max] up[r_max] last_col[n_t] red[8] | pre16[n_t][N] i16 | d_lim
+//   down[n_t][r_pitch] up[n_t][r_pitch] last_col[n_t] red[2][8] | pre16[n_t][N] i16 | d_lim
 //   | cell records [N][2 r_tab + 4] (see StTab)
 // TABLES: the cost / predecessor tables are written to global memory.
 // RTK >= 0: an instance for batches with at most RTK blocked intervals per layer (layers
@@ -464,15 +467,17 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     sh.acc = sh.ch_cur + 2 * N;    // index n + (n_s-1), n in [-(n_s-1), n_s-1]
     sh.jerk2 = sh.acc + 2 * N;     // same index, layer i == 2
     sh.jerk3 = sh.jerk2 + 2 * N;   // index m + 2(n_s-1), layers i >= 3
-    // blocked intervals: one layer's (staged layer by layer) or, when they are few, every layer's
-    const bool stage_all = a.stage_all != 0;
-    const int R_slots = stage_all ? R_max * n_t : R_max;
+    // blocked intervals of every time layer, r_pitch slots each, staged once at the start; a layer
+    // with more intervals than that (it takes the thread-per-cell relaxation anyway) reads them
+    // from global memory
+    const int pitch = a.r_pitch;
+    const int R_slots = pitch * n_t;
     double *down_all = sh.jerk3 + 4 * N, *up_all = down_all + R_slots;
     sh.down = down_all;
     sh.up = up_all;
     double *last_col = up_all + R_slots;
-    double *red = last_col + n_t;
-    sh.pre16 = (short *)(red + 8);
+    double *red = last_col + n_t; // [2][8]: the layer minimum per wave, buffers alternating by layer
+    sh.pre16 = (short *)(red + 16);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
     StTab tb; // placed by offset from smem so the pointers stay LDS pointers
     tb.rec = smem + st_tab_offset(N, R_slots, n_t) / 8;
@@ -528,52 +533,27 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         tb.quiet(j)[0] = 0x7fffffff;
         tb.quiet(j)[1] = 0;
     }
-    if (stage_all) {
-        for (int q = tid; q < (n_t - 1) * R_max; q += nt) {
-            const int i = 1 + q / R_max, k = q - (i - 1) * R_max;
-            if (k < min(max(a.n_reg[(size_t)b * n_t + i], 0), R_max)) {
-                down_all[i * R_max + k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
-                up_all[i * R_max + k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
-            }
+    for (int q = tid; q < (n_t - 1) * pitch; q += nt) {
+        const int i = 1 + q / pitch, k = q - (i - 1) * pitch;
+        const int R_i = min(max(a.n_reg[(size_t)b * n_t + i], 0), R_max);
+        if (R_i <= pitch && k < R_i) {
+            down_all[i * pitch + k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
+            up_all[i * pitch + k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
         }
     }
     __syncthreads();
     const int d_lim = *d_lim_sh;
     double m_prev = 0.0; // minimum of cost_prev
 
-    // the interval count of a layer is fetched while the layer before it is relaxed; so are the
-    // intervals themselves when they are staged layer by layer (one per thread; any beyond
-    // blockDim are read directly)
+    // the interval count of a layer is fetched while the layer before it is relaxed
     int R_next = min(max(a.n_reg[(size_t)b * n_t + 1], 0), R_max);
-    double pf_down = 0.0, pf_up = 0.0;
-    if (!stage_all && tid < R_next) {
-        pf_down = a.s_down[((size_t)b * n_t + 1) * R_max + tid];
-        pf_up = a.s_up[((size_t)b * n_t + 1) * R_max + tid];
-    }
     for (int i = 1; i < n_t; ++i) {
         const int R = R_next;
-        if (stage_all) {
-            sh.down = down_all + i * R_max;
-            sh.up = up_all + i * R_max;
-        } else {
-            // (the layer before this one has finished with the staging row: the barrier at its end)
-            if (tid < R) {
-                sh.down[tid] = pf_down;
-                sh.up[tid] = pf_up;
-            }
-            for (int k = tid + nt; k < R; k += nt) {
-                sh.down[k] = a.s_down[((size_t)b * n_t + i) * R_max + k];
-                sh.up[k] = a.s_up[((size_t)b * n_t + i) * R_max + k];
-            }
-        }
-        if (i + 1 < n_t) {
-            R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
-            if (!stage_all && tid < R_next) {
-                pf_down = a.s_down[((size_t)b * n_t + i + 1) * R_max + tid];
-                pf_up = a.s_up[((size_t)b * n_t + i + 1) * R_max + tid];
-            }
-        }
-        if (!stage_all) __syncthreads();
+        const bool staged = R <= pitch; // else: in global memory
+        sh.down = down_all + i * pitch;
+        sh.up = up_all + i * pitch;
+        const double *g_down = a.s_down + ((size_t)b * n_t + i) * R_max, *g_up = a.s_up + ((size_t)b * n_t + i) * R_max;
+        if (i + 1 < n_t) R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
         double m_loc = MP_INF;
         if (i == 1) {
             // only p_j = 0 (speed_planner.py:96-100)
@@ -583,8 +563,14 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                 double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
                 double jk = __ddiv_rn(ac, dt);
                 StCellLds cell;
-                cell.init(s, sh.down, sh.up, R);
-                double ob = cell.ob(s, sh.front(j));
+                double ob;
+                if (staged) {
+                    cell.init(s, sh.down, sh.up, R);
+                    ob = cell.ob(s, sh.front(j));
+                } else {
+                    cell.init(s, g_down, g_up, R);
+                    ob = cell.ob(s, sh.front(j));
+                }
                 double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed(j)), __dmul_rn(__dmul_rn(ac, ac), dt)),
                                         __dmul_rn(__dmul_rn(jk, jk), dt));
                 sh.cost_cur(j) = best;
@@ -596,12 +582,14 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             }
         } else if (RTK >= 0) {
             if constexpr (RTK >= 0) {
-                if (R <= RTK && RTK <= a.r_tab)
+                if (R <= RTK && RTK <= a.r_tab && staged)
                     m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                else if (staged)
+                    m_loc = st_relax_layer<StCellLds>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
                 else
-                    m_loc = st_relax_layer<StCellLds>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                    m_loc = st_relax_layer<StCellLds>(a, sh, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
             }
-        } else if (R <= 8 && (R == 7 ? 8 : R) <= a.r_tab) { // 7 intervals run as 8 with one padded slot
+        } else if (R <= 8 && (R == 7 ? 8 : R) <= a.r_tab && staged) { // 7 intervals run as 8 with one padded slot
 #define ST_SPLIT_CASE(RT)                                                                                   \
     m_loc = a.lanes_per_cell == 4 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
                     : st_relax_layer_split<RT, 8>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
@@ -616,18 +604,20 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             default: ST_SPLIT_CASE(8); break;
             }
 #undef ST_SPLIT_CASE
+        } else if (!staged) {
+            m_loc = st_relax_layer<StCellLds>(a, sh, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
         } else {
             switch (R) {
-            case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 1: m_loc = st_relax_layer<StCell<1>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 2: m_loc = st_relax_layer<StCell<2>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 3: m_loc = st_relax_layer<StCell<3>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 4: m_loc = st_relax_layer<StCell<4>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 5: m_loc = st_relax_layer<StCell<5>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 6: m_loc = st_relax_layer<StCell<6>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 1: m_loc = st_relax_layer<StCell<1>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 2: m_loc = st_relax_layer<StCell<2>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 3: m_loc = st_relax_layer<StCell<3>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 4: m_loc = st_relax_layer<StCell<4>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 5: m_loc = st_relax_layer<StCell<5>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 6: m_loc = st_relax_layer<StCell<6>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
             case 7:
-            case 8: m_loc = st_relax_layer<StCell<8>>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            default: m_loc = st_relax_layer<StCellLds>(a, sh, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            case 8: m_loc = st_relax_layer<StCell<8>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            default: m_loc = st_relax_layer<StCellLds>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
             }
         }
         // padding cells keep the initial values
@@ -635,14 +625,17 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             if (cost_g) cost_g[(size_t)i * N + j] = 0.0;
             if (pre_g) pre_g[(size_t)i * N + j] = -1;
         }
+        // (a layer that takes the thread-per-cell relaxation has no barrier of its own: a wave
+        // may be writing the next layer's minimum while another still reads this one's, hence
+        // the two buffers)
+        double *red_i = red + 8 * (i & 1);
         m_loc = wave_min_f64(m_loc);
-        if ((tid & (MP_WAVE - 1)) == 0) red[wave] = m_loc;
+        if ((tid & (MP_WAVE - 1)) == 0) red_i[wave] = m_loc;
         __syncthreads();
         if (tid == 0) last_col[i] = sh.cost_cur(n_s - 1);
-        m_prev = red[0];
-        for (int w = 1; w < nw; ++w) m_prev = red[w] < m_prev ? red[w] : m_prev;
-        // the two cost rows swap roles; the next layer overwrites `red` and the other row
-        // only after its own first barrier
+        m_prev = red_i[0];
+        for (int w = 1; w < nw; ++w) m_prev = red_i[w] < m_prev ? red_i[w] : m_prev;
+        // the two cost rows swap roles: the next layer writes the row this one read
         double *row = sh.ch_prev;
         sh.ch_prev = sh.ch_cur;
         sh.ch_cur = row;
@@ -677,6 +670,15 @@ template <bool TABLES>
 __global__ void st_dp_kernel(StDev a)
 {
     st_dp_body<TABLES, -1, 0>(a);
+}
+
+// The kernel that holds every path, without the tables: 101 registers would leave it at four
+// waves per SIMD; at five (96 registers, 12 B of scratch) the whole replan's speed search, whose
+// workgroups mostly wait for LDS round trips and barriers, takes 0.115 instead of 0.134 ms per
+// 4096 scenes (six waves: 56 B of scratch, 0.119).
+__attribute__((amdgpu_waves_per_eu(5, 5))) __global__ void st_dp_plain_kernel(StDev a)
+{
+    st_dp_body<false, -1, 0>(a);
 }
 
 #ifndef ST_WAVES_PER_EU
@@ -1025,18 +1027,19 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     if (r_tab > 8 || r_tab == 7) r_tab = 8; // the split path keeps a cell's intervals in registers (7 run as 8)
     while (r_tab > 0 && st_tab_bytes(n_s_max, r_tab) > 40 * 1024) --r_tab;
     if (mp_knob_st_generic() == 2) r_tab = 0; // tests: no cell tables, every layer with intervals by a thread per cell
-    // the intervals of every layer in LDS from the start when that is a few kilobytes: a layer
-    // then begins without a barrier
+    // the intervals of every layer sit in LDS from the start (a layer then begins without a
+    // barrier): as many slots per layer as the caller's bound when that is a few kilobytes, else
+    // the 8 the lanes-per-cell relaxation takes; a layer with more is read from global memory
     const int r_slots_1 = r_max > 0 ? r_max : 1;
-    const int stage_all = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024;
-    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), stage_all, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    const int r_pitch = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024 ? r_slots_1 : 8;
+    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_tab_offset(n_s_max, stage_all ? a.r_max * n_t : a.r_max, n_t) + st_tab_bytes(n_s_max, r_tab);
+    size_t lds = st_tab_offset(n_s_max, r_pitch * n_t, n_t) + st_tab_bytes(n_s_max, r_tab);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
@@ -1065,7 +1068,11 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         case 5: ST_R_LAUNCH(5); break;
         case 6: ST_R_LAUNCH(6); break;
         case 8: ST_R_LAUNCH(8); break;
-        default: hipLaunchKernelGGL(st_dp_kernel<false>, grid, block, lds, st, a); break;
+        default:
+            // (a small batch leaves the GPU mostly empty: the build without scratch is the quicker one there)
+            if (B > 512) hipLaunchKernelGGL(st_dp_plain_kernel, grid, block, lds, st, a);
+            else hipLaunchKernelGGL(st_dp_kernel<false>, grid, block, lds, st, a);
+            break;
     }
 #undef ST_R_LAUNCH
     return st_launch_check("mp_st_dp");

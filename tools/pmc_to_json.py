@@ -19,8 +19,8 @@ k = {}
 for line in open(src):
     m = re.match(r"(\S.*?)\s+(\S+)\s+n=\d+\s+mean=(\S+)", line)
     name = m.group(1).split("<")[0] if m else None   # template instances count under the kernel's name
-    if name == "st_dp_r_kernel":
-        name = "st_dp_kernel"   # the instances per interval bound are the same kernel body
+    if name in ("st_dp_r_kernel", "st_dp_plain_kernel"):
+        name = "st_dp_kernel"   # the instances per interval bound and the five-wave build are the same kernel body
     if name in KERNELS:
         if m.group(1).startswith("sl_plan_kernel<"):
             targs = [t.strip() for t in m.group(1)[len("sl_plan_kernel<"):].rstrip(">").split(",")]
