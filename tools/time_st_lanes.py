@@ -17,18 +17,19 @@ from motion_planning_amd import _lib, batch as mb
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     sc = bench.make_scenarios(0, B)
-    args = (mb.to_dev(sc["st_n_s"], torch.int32), mb.to_dev(sc["down"]), mb.to_dev(sc["up"]),
+    n_cells = int(os.environ.get("ST_AB_N", bench.ST_N_S))   # another grid width (what LDS holds changes with it)
+    args = (mb.to_dev(np.minimum(sc["st_n_s"], n_cells), torch.int32), mb.to_dev(sc["down"]), mb.to_dev(sc["up"]),
             mb.to_dev(sc["n_reg"], torch.int32), mb.to_dev(sc["cur_vel"]), bench.SPEED_LIM)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(label):
         out = None
         for _ in range(3):
-            out = mb.st_dp(*args, want_tables=False, n_s_max=bench.ST_N_S, out=out)
+            out = mb.st_dp(*args, want_tables=False, n_s_max=n_cells, out=out)
         ts = []
         for _ in range(20):
             e0.record()
-            out = mb.st_dp(*args, want_tables=False, n_s_max=bench.ST_N_S, out=out)
+            out = mb.st_dp(*args, want_tables=False, n_s_max=n_cells, out=out)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
