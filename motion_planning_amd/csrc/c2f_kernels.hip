@@ -518,18 +518,30 @@ struct CvDev {
 //   mode 0: samples get_arange(t0, t0 + np.sum(T), dt)   (SLMap.path_sampling, sl_map.py:115-118)
 //   mode 1: samples get_arange(t0, t_last, dt)           (SpeedPlanner.plan, speed_planner.py:47)
 //   mode 2: samples given by the caller                  (path_sampling(curve, False, ss))
-// Dynamic LDS: tq[q_max] tsum[q_max] (double) seg[q_max] (int).
+// Dynamic LDS, sized by the curve's knot slots (ns = n_knots_max - 1 segment slots) so that short
+// splines leave room for many workgroups per CU: T[ns] coef[6 ns] vv[ns + 1] aa[ns + 1] Scum[ns],
+// then tq[q_max] tsum[q_max] (double) seg[q_max] (int); cv_lds_bytes gives the total.
 // (the body of curve_eval_kernel for curve b with npts knots; every thread of the
 // workgroup calls it, and a workgroup may call it again after a barrier)
+__host__ __device__ __forceinline__ int cv_seg_slots(int n_knots_max)
+{
+    return n_knots_max - 1 < RL_SEG_CAP ? (n_knots_max > 1 ? n_knots_max - 1 : 1) : RL_SEG_CAP;
+}
+__host__ __device__ __forceinline__ size_t cv_lds_bytes(int n_knots_max, int q_max)
+{
+    return ((size_t)10 * cv_seg_slots(n_knots_max) + 2 + 2 * (size_t)q_max) * sizeof(double) + (size_t)q_max * sizeof(int);
+}
+
 __device__ __forceinline__ void curve_eval_scene(const CvDev &a, const int b, const int npts, double *smem)
 {
-    __shared__ double T[RL_SEG_CAP], coef[RL_SEG_CAP * 6], vv[RL_SEG_CAP + 1], aa[RL_SEG_CAP + 1];
-    __shared__ double Scum[RL_SEG_CAP]; // running end of the current segment in calc_point_arr's walk
     __shared__ double sc_d[2];          // fill step and end of the sample set
     __shared__ int sc_i[4];             // n samples, status, start segment / samples on the grid, ascending
     const int tid = threadIdx.x, nt = blockDim.x;
-    double *tq = smem, *tsum = smem + a.q_max;
-    int *seg = (int *)(smem + 2 * (size_t)a.q_max);
+    const int ns = cv_seg_slots(a.n_knots_max);
+    double *T = smem, *coef = T + ns, *vv = coef + 6 * ns, *aa = vv + ns + 1;
+    double *Scum = aa + ns + 1; // running end of the current segment in calc_point_arr's walk
+    double *tq = Scum + ns, *tsum = tq + a.q_max;
+    int *seg = (int *)(tsum + a.q_max);
     const int n = npts - 1;
     const double *kt = a.knots_t + (size_t)b * a.n_knots_max;
     const double *kx = a.knots_x + (size_t)b * a.n_knots_max;
@@ -855,9 +867,9 @@ extern "C" int mp_f2c_batch(int32_t n_pts, const double *s, const double *l, con
     return c2f_launch_check("mp_f2c_batch");
 }
 
-// Spline kernels: dynamic LDS on top of the static arrays of curve_eval_scene (knots,
-// coefficients, running sums: below 12 KB) must stay within the 64 KB a workgroup gets here.
-#define CV_STATIC_LDS (12 * 1024)
+// Spline kernels: dynamic LDS on top of the few static words of curve_eval_scene must stay
+// within the 64 KB a workgroup gets here.
+#define CV_STATIC_LDS 256
 static int cv_lds_check(const char *what, const char *dim, int value, size_t lds)
 {
     if (lds + CV_STATIC_LDS <= 64 * 1024) return MP_OK;
@@ -876,16 +888,18 @@ static int cv_threads(int n_points)
 // The two fused stages of the whole replan (plan_glue.h).
 int mp_plan_path_stage(int32_t B, const PlanPathDev &a, void *stream)
 {
-    size_t lds = (size_t)a.p_max * (2 * sizeof(double) + sizeof(int));
+    size_t lds = cv_lds_bytes(a.n_s_max + 1, a.p_max);
     lds = (lds + 15) & ~(size_t)15;
     if (int rc = cv_lds_check("mp_plan_scenes (path spline)", "p_max", a.p_max, lds)) return rc;
-    hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(cv_threads(a.p_max)), lds, (hipStream_t)stream, a);
+    // (as in the tail stage: one wave per scene in a large batch)
+    const int threads = (B >= 1024 && mp_knob_cv_threads() <= 0) ? MP_WAVE : cv_threads(a.p_max);
+    hipLaunchKernelGGL(plan_path_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, a);
     return c2f_launch_check("mp_plan_scenes (path spline)");
 }
 
 int mp_plan_tail_stage(int32_t B, const PlanTailDev &a, void *stream)
 {
-    size_t lds = (size_t)a.q_max * (2 * sizeof(double) + sizeof(int));
+    size_t lds = cv_lds_bytes(a.n_t > a.n_pk_max ? a.n_t : a.n_pk_max, a.q_max); // both splines of the stage
     const bool table_larger = lds < (size_t)a.m_max * sizeof(double);
     if (table_larger) lds = (size_t)a.m_max * sizeof(double); // the arc-length table
     lds = (lds + 15) & ~(size_t)15;
@@ -915,7 +929,7 @@ extern "C" int mp_curve_eval(int32_t B, const double *knots_t, const double *kno
     }
     CvDev a{n_knots_max, q_max, mode, knots_t, knots_x, n_knots, vec, dt, query, n_query, out_t, out_x, out_dx,
             n_out, status};
-    size_t lds = (size_t)q_max * (2 * sizeof(double) + sizeof(int));
+    size_t lds = cv_lds_bytes(n_knots_max, q_max);
     lds = (lds + 15) & ~(size_t)15;
     if (int rc = cv_lds_check("mp_curve_eval", "q_max", q_max, lds)) return rc;
     hipLaunchKernelGGL(curve_eval_kernel, dim3(B), dim3(q_max <= 128 ? 128 : 256), lds, (hipStream_t)stream, a);
