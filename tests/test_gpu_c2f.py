@@ -335,3 +335,27 @@ def test_refline_tables_same_bits_for_every_workgroup_size(knob):
         a, r = getattr(small, f), getattr(ref, f)[:7]
         k = ok[:7]
         assert torch.equal(torch.nan_to_num(a[k]), torch.nan_to_num(r[k])), ("small batch", f)
+
+
+def test_refline_tables_of_a_two_kilometre_line(oracle):
+    """The largest line the tables take: 128 segments and 3841 samples, whose per-segment arrays
+    and sample arrays together exceed what a launch gets without asking for it (78 KB of LDS)."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(5)
+    xs = -2.0 + np.concatenate([[0.0], np.cumsum(np.full(128, 15.0))])
+    ys = 40.0 * np.sin(xs / 300.0) + rng.uniform(-0.2, 0.2, xs.size)
+    ego = np.array([[700.3, 31.0]])
+    t = mb.refline_tables(xs[None], ys[None], np.array([xs.size], np.int32), np.zeros(1), ego, m_max=4096)
+    torch.cuda.synchronize()
+    assert int(t.status[0]) == 1
+    conv = oracle.CartesianFrenetConverter(ego[0, 0], ego[0, 1], xs, ys, 0.0)
+    tx, xx, S, th, kr = conv.tables()
+    M = int(t.M[0])
+    assert M == len(tx) == 3841
+    assert np.array_equal(t.tab_x[0, :M].cpu().numpy(), tx)
+    close(t.tab_y[0, :M].cpu().numpy(), xx)
+    close(t.tab_s[0, :M].cpu().numpy(), S, rtol=1e-11)
+    close(t.tab_theta[0, :M].cpu().numpy(), th)
+    close(t.tab_kappa[0, :M].cpu().numpy(), kr, rtol=1e-10)
+    close(t.origin[0, :2].cpu().numpy(), [conv.rx_ori, conv.ry_ori])
