@@ -572,15 +572,22 @@ class Job:
 def timed_blocks(job, step, drain, steps, reps):
     """`reps` timed blocks of exactly `steps` steps, each bracketed by barrier + device
     synchronisation on both sides; returns the blocks' seconds (max over ranks)."""
+    import gc
     secs = []
-    for _ in range(reps):
-        job.fence()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        drain()
-        job.fence()
-        secs.append(time.perf_counter() - t0)
+    gc_was_on = gc.isenabled()
+    gc.disable()   # a collection inside a block of a few milliseconds shows up as a block several times as long
+    try:
+        for _ in range(reps):
+            job.fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            drain()
+            job.fence()
+            secs.append(time.perf_counter() - t0)
+    finally:
+        if gc_was_on:
+            gc.enable()
     return job.max_over_ranks(secs)
 
 
@@ -781,7 +788,8 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
     roofs = [
         stage_roof("ST speed DP", "st_dp_kernel", flop_st,
                    "(30 + 9 R) flop per ST edge over the scenes that reach the speed search, R = that layer's "
-                   "interval count"),
+                   "interval count; the launch is st_dp_plain_kernel, the build of st_dp_kernel's body for large "
+                   "batches (every relaxation path, no tables, five waves per SIMD)"),
         stage_roof("front end (Frenet map, obstacle list)", "plan_frontend_kernel", flop_fe,
                    "(7 M + 40) flop per point to Frenet, M = the scene's reference-line samples; the kernel "
                    "compares only the samples of the blocks whose bounding box can hold the nearest one"),
@@ -1141,7 +1149,7 @@ def bench_lattice(args, job):
     split_secs = None
     if args.streams > 1 and B >= 64 * args.streams:
         split = SplitLoop(sc, prm, gather, args.streams, bool(args.maps))
-        for _ in range(max(2, args.warmup)):
+        for _ in range(max(2, args.warmup) + steps):   # (as many as a timed block: the first blocks of new streams are slow)
             split.step()
         gather.drain()
         split_secs = timed_blocks(job, split.step, gather.drain, steps, reps)
