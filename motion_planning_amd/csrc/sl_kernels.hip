@@ -645,7 +645,8 @@ __device__ __forceinline__ void write_skipped(const SlDev &a, int b, int n_sm, i
 //   | laySorted[n_s] u8 (padded to 4) | locL[n_s] u8 (padded to 4: layers that need no exchange)
 //   | runL[n_s] u8 (padded to 4) | rowL[n_s] u8 (padded to 4: the layer's predecessor row, 0xff: none)
 //   | pair_lay[cap] u16 (padded to 4: layer of every stored pair) | idx8[idx_rows*n_l] u8 (padded to 8)
-//   | lrow[n_lp] double (the shared lateral row) | wmask[nt] u64 (per wave: lanes hit, per layer of a run)
+//   | lrow[n_lp] double (the shared lateral row) | wmask[2][nt] u64 (per wave: lanes hit, per layer of a run;
+//   two buffers, taken in turn by the runs)
 // Predecessor rows are kept only for layers that looked at other lanes (the others keep every
 // lane), handed out in the order the layers are relaxed; a.idx_rows of them fit.
 // SHARED_ROW: one lateral row for all layers (l_rstride == 0); MAPS: cost map / index map requested
@@ -738,6 +739,8 @@ __global__ void sl_plan_kernel(SlDev a)
     }
     if (!rstride)
         for (int i = tid; i < n_l; i += nt) lrow[i] = lbase[i]; // the lateral row every layer shares (for the runs below)
+    wmask[tid] = 0ull; // both buffers of the runs' masks
+    wmask[nt + tid] = 0ull;
     const bool layers_ascend = !__syncthreads_or(out_of_order);
     {
         // largest |l - mid| over the lattice (bounds every straight-edge cost)
@@ -831,6 +834,7 @@ __global__ void sl_plan_kernel(SlDev a)
     double c_top = MP_INF;  // upper bound of every accumulated cost of the layer being relaxed
     double cost_own = 0.0;  // this thread's node of the previous layer
     bool local = false;     // the layer being relaxed needs no exchange between lanes
+    int run_par = 0;        // which of the two mask buffers the next run of layers without exchange takes
     int row_next = 0;       // predecessor rows handed out so far
     bool rows_short = false; // a layer that walked found no row left: the path cannot be traced back here
     auto is_local = [&](double top, double w_inv_l) {
@@ -887,18 +891,16 @@ __global__ void sl_plan_kernel(SlDev a)
                 // pair): it finds the first lane at or beyond the obstacle, tests the two lanes
                 // next to the obstacle (if neither is hit, none is), bisects for the first and
                 // the last lane hit with that very test, and ORs the range into the mask of
-                // the pair's layer.  Every wave does this for its own 64 lanes, in its own
-                // masks, so the waves need not meet.
+                // the pair's layer: one 64-bit mask per layer of the run and wave.  The pairs
+                // are spread over the lanes of the whole workgroup (a pair's range may reach
+                // into several waves' lanes), and one barrier stands between the ORs and the
+                // reads.  The masks are double-buffered by run: a wave that is a run ahead ORs
+                // into the other buffer, and a wave zeroes its entries right after reading
+                // them, which happens before anyone passes the next run's barrier.
                 const int lane = tid & (MP_WAVE - 1), lane0 = tid - lane; // first lattice lane of this wave
-                unsigned long long *wm = wmask + lane0;
-                // The masks pass from the lanes that write them to the lanes that read them
-                // through LDS inside one wave: atomic accesses with fences of wave scope, so that
-                // the compiler neither keeps a lane's own zero in a register (a lane that takes
-                // no pair still reads what the others wrote) nor moves the accesses across.
-                __hip_atomic_store(&wm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int e = e_begin + lane; e < e_end; e += MP_WAVE) {
+                unsigned long long *wm_run = wmask + run_par * nt;
+                run_par ^= 1;
+                for (int e = e_begin + tid; e < e_end; e += nt) {
                     const double ol_e = pair_ol[e], q_e = pair_ds2[e];
                     const int li = (int)pair_lay[e] - s_in;
                     auto pred = [&](int i) {
@@ -925,17 +927,17 @@ __global__ void sl_plan_kernel(SlDev a)
                             if (pred(mid)) b0 = mid; else b1 = mid - 1;
                         }
                     }
-                    // lanes a0 .. b0 of the lattice, as bits of this wave's 64
-                    const int lo = max(a0 - lane0, 0), hi = min(b0 - lane0, MP_WAVE - 1);
-                    if (lo <= hi) {
+                    // lanes a0 .. b0 of the lattice, as bits of the 64 of every wave they reach
+                    for (int w0 = a0 & ~(MP_WAVE - 1); w0 <= b0; w0 += MP_WAVE) {
+                        const int lo = max(a0 - w0, 0), hi = min(b0 - w0, MP_WAVE - 1);
                         const unsigned long long m = (~0ull >> (MP_WAVE - 1 - (hi - lo))) << lo;
-                        atomicOr(&wm[li], m);
+                        atomicOr(&wm_run[w0 + li], m);
                     }
                 }
+                __syncthreads();
                 // lane i now reads the mask of layer s + i; the loop below fetches it lane by lane
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const unsigned long long wm_i = __hip_atomic_load(&wm[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const unsigned long long wm_i = wm_run[lane0 + lane];
+                wm_run[lane0 + lane] = 0ull;
                 const unsigned wm_lo = (unsigned)wm_i, wm_hi = (unsigned)(wm_i >> 32);
                 const unsigned long long my_bit = 1ull << lane;
                 for (int i = 0; i < n_run; ++i) {
@@ -1880,7 +1882,7 @@ static size_t sl_plan_lds_bytes(int n_s, int n_l, int cap, int rows)
     bytes += 4 * (((size_t)n_s + 3) & ~(size_t)3) + (size_t)rows * n_l;
     bytes += 2 * ((size_t)cap + (cap & 1));                     // layer of every stored pair
     bytes = (bytes + 7) & ~(size_t)7;
-    bytes += ((size_t)((n_l + 1) & ~1) + (size_t)((n_l + 63) / 64) * 64) * sizeof(double); // lateral row, run masks
+    bytes += ((size_t)((n_l + 1) & ~1) + 2 * (size_t)((n_l + 63) / 64) * 64) * sizeof(double); // lateral row, run masks
     return (bytes + 15) & ~(size_t)15;
 }
 
