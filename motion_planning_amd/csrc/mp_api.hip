@@ -27,11 +27,11 @@ extern "C" const char *mp_last_error(void) { return g_err; }
 // only through mp_set_knob.  -1 = not set (the library's normal choice).
 // ---------------------------------------------------------------------------
 enum { KNOB_SL_NARROW, KNOB_SL_PAIR_CAP, KNOB_ST_REGIONS_ONCE, KNOB_ST_THREADS, KNOB_RL_THREADS, KNOB_FE_THREADS,
-       KNOB_ST_GENERIC, KNOB_ORDER, KNOB_ST_LANES, KNOB_SL_ROWS, KNOB_CV_THREADS, KNOB_COUNT };
+       KNOB_ST_GENERIC, KNOB_ORDER, KNOB_ST_LANES, KNOB_SL_ROWS, KNOB_CV_THREADS, KNOB_ST_PREFIX, KNOB_COUNT };
 static const char *const g_knob_names[KNOB_COUNT] = {"MP_SL_NARROW", "MP_SL_PAIR_CAP", "MP_ST_REGIONS_ONCE",
                                                      "MP_ST_THREADS", "MP_RL_THREADS", "MP_FE_THREADS",
                                                      "MP_ST_GENERIC", "MP_ORDER", "MP_ST_LANES", "MP_SL_ROWS",
-                                                     "MP_CV_THREADS"};
+                                                     "MP_CV_THREADS", "MP_ST_PREFIX"};
 static std::atomic<int> g_knobs[KNOB_COUNT];
 static std::once_flag g_knobs_once;
 
@@ -68,6 +68,7 @@ int mp_knob_st_threads() { return knob(KNOB_ST_THREADS); }
 int mp_knob_rl_threads() { return knob(KNOB_RL_THREADS); }
 int mp_knob_fe_threads() { return knob(KNOB_FE_THREADS); }
 int mp_knob_cv_threads() { return knob(KNOB_CV_THREADS); }
+int mp_knob_st_prefix() { return knob(KNOB_ST_PREFIX); }
 int mp_knob_st_generic() { return knob(KNOB_ST_GENERIC); }
 int mp_knob_order() { return knob(KNOB_ORDER); }
 int mp_knob_st_lanes() { return knob(KNOB_ST_LANES); }

@@ -42,6 +42,7 @@ struct StDev {
     int32_t n_t, n_s_max, r_max, r_tab; // r_tab: interval slots per cell in the LDS cell tables
     int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
     int32_t r_pitch;                    // interval slots per time layer in LDS (layers with more are read from global memory)
+    int32_t k_prefix;                   // > 0: cells 0..k_prefix are planned first, for a bound on the plan's cost (see st_dp_body)
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -153,6 +154,7 @@ struct StCellLds {
 // is then one pass (measured, one plan per call, replayed graph: 29 / 61 / 101 cells take
 // 50 / 60 / 73 us with 8 lanes and a workgroup as wide as the grid needs, 56 / 78 / 96 us with 4).
 int mp_knob_st_lanes();
+int mp_knob_st_prefix();
 static inline int st_lanes_per_cell(int B, int n_s_max)
 {
     if (mp_knob_st_lanes() > 0) return mp_knob_st_lanes(); // development aid
@@ -170,13 +172,26 @@ struct StSh {
 
 // History word of cell j of layer i, whose predecessor bp has just been fixed, as the next
 // layer reads it when j is a predecessor there (see the LDS rows above): next to the cell's cost.
-__device__ __forceinline__ void st_store_hist(const StSh &sh, int i, int N, int j, int bp)
+__device__ __forceinline__ int st_store_hist(const StSh &sh, int i, int N, int j, int bp)
 {
     const int lo = 8 * (bp - 2 * j);
     int hi = lo; // layer 2 reads the acceleration offset twice (its jerk has no third predecessor)
     if (i >= 2) hi = 8 * (3 * bp - (int)sh.pre16[(size_t)(i - 1) * N + bp] - 3 * j);
-    *(int *)(sh.ch_cur + 2 * j + 1) = (lo & 0xffff) | (hi << 16);
+    const int word = (lo & 0xffff) | (hi << 16);
+    *(int *)(sh.ch_cur + 2 * j + 1) = word;
+    return word;
 }
+
+// The cells a relaxation call takes: j_lo..j_hi of the layer.  u_cap: a number the plan's final
+// cost cannot exceed (MP_INF: none known); a candidate whose cost is certain to exceed it need
+// not be priced (see st_dp_body).  keep_cost / keep_hist (may be null): where the cells' costs
+// and history words of this layer are kept beside the cost row, indexed by cell.
+struct StRange {
+    int j_lo, j_hi;
+    double u_cap;
+    double *keep_cost;
+    int *keep_hist;
+};
 
 // All cells of time layer i >= 2 owned by this thread.
 //
@@ -192,7 +207,7 @@ __device__ __forceinline__ void st_store_hist(const StSh &sh, int i, int N, int 
 // down / up: the layer's intervals, in LDS or (a layer with more intervals than LDS has slots
 // for) in global memory; every call site passes one kind, so the loads are typed.
 template <class CELL>
-__device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh, const double *down,
+__device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh, const StRange &rg, const double *down,
                                                  const double *up, int i, int n_s, int N, int R,
                                                  int d_lim, double m_prev, double *cost_g, int32_t *pre_g)
 {
@@ -200,7 +215,7 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
     const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
     const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
     double m_loc = MP_INF;
-    for (int j = threadIdx.x; j < n_s; j += blockDim.x) {
+    for (int j = rg.j_lo + threadIdx.x; j <= rg.j_hi; j += blockDim.x) {
         const double s = __dmul_rn((double)j, ds);
         CELL cell;
         cell.init(s, down, up, R);
@@ -228,7 +243,11 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
         }
         sh.cost_cur(j) = best;
         sh.pre16[(size_t)i * N + j] = (short)bp;
-        st_store_hist(sh, i, N, j, bp);
+        const int hist = st_store_hist(sh, i, N, j, bp);
+        if (rg.keep_cost) {
+            rg.keep_cost[j] = best;
+            rg.keep_hist[j] = hist;
+        }
         if (cost_g) cost_g[(size_t)i * N + j] = best;
         if (pre_g) pre_g[(size_t)i * N + j] = bp;
         m_loc = best < m_loc ? best : m_loc;
@@ -261,6 +280,27 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 {
     return (size_t)N * st_rec_stride(r_tab) * sizeof(double);
 }
+// Cells the records are laid out for: the whole grid, or the larger of the two sweeps' shares
+// (cells 0..k_prefix, then the rest; see st_dp_body).
+__host__ __device__ __forceinline__ int st_rec_cells(int N, int k_prefix)
+{
+    if (k_prefix <= 0) return N;
+    const int first = k_prefix + 1, rest = N - first;
+    return first > rest ? first : rest;
+}
+// Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
+// layers' minima over them (double [n_t]) and their history words (int [n_t][k+1]).
+__host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int k_prefix)
+{
+    const size_t b = st_tab_offset(N, r_slots, n_t) + st_tab_bytes(st_rec_cells(N, k_prefix), r_tab);
+    return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t st_keep_bytes(int n_t, int k_prefix)
+{
+    if (k_prefix <= 0) return 0;
+    const size_t cells = (size_t)n_t * (k_prefix + 1);
+    return (cells + n_t) * sizeof(double) + cells * sizeof(int);
+}
 
 // All cells of time layer i >= 2, ST_SPLIT lanes per cell.
 //
@@ -282,8 +322,11 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 // walks short (three or four steps per lane on a 97-cell grid), so what a pass over the
 // cells costs outside the walk matters as much as the walk: a cell's intervals, fire
 // distances and flags are one record, read with constant offsets from one address.
-template <int RT, int ST_SPLIT>
-__device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb, int i,
+// CAPPED: rg.u_cap bounds the plan's final cost, and a walk also stops once everything left
+// of it is certain to cost more than that.  Records are indexed from the range's first cell.
+template <int RT, int ST_SPLIT, bool CAPPED = false>
+__device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb,
+                                                       const StRange &rg, int i,
                                                        int n_s, int N, int R, int d_lim, double m_prev,
                                                        double *cost_g, int32_t *pre_g)
 {
@@ -294,12 +337,13 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // plan and put back by whoever read them last, see below)
     const double front_step = sh.front(n_s > 1 ? 1 : 0);
     const double inv_front_step = front_step > 0.0 ? 1.0 / front_step : 0.0; // for an estimate only
-    // q / n_s by multiplication: exact while q * n_s < 2^32 (q < 8 * n_s, n_s <= 1024); a
-    // single-cell grid has no 32-bit multiplier and needs none
-    const unsigned n_s_magic = n_s > 1 ? 0xffffffffu / (unsigned)n_s + 1u : 0u;
-    for (int q = tid; q < n_s * RT; q += nt) {
-        const int k = n_s > 1 ? (int)__umulhi((unsigned)q, n_s_magic) : q, j = q - k * n_s;
-        double *rec = tb.cell(j);
+    // q / n_c by multiplication: exact while q * n_c < 2^32 (q < 8 * n_c, n_c <= 1024); a
+    // single-cell range has no 32-bit multiplier and needs none
+    const int j_lo = rg.j_lo, n_c = rg.j_hi - rg.j_lo + 1;
+    const unsigned n_c_magic = n_c > 1 ? 0xffffffffu / (unsigned)n_c + 1u : 0u;
+    for (int q = tid; q < n_c * RT; q += nt) {
+        const int k = n_c > 1 ? (int)__umulhi((unsigned)q, n_c_magic) : q, j = j_lo + (q - k * n_c);
+        double *rec = tb.cell(j - j_lo);
         double dnk = MP_INF, ck = 0.0; // slots beyond the layer's intervals never fire and add exact zeros
         unsigned e_fire = 0xffffu;
         if (k < R) {
@@ -315,10 +359,10 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 while (dq > 0 && s >= __dsub_rn(dnk, sh.front(dq - 1))) --dq;
                 while (dq < n_s && !(s >= __dsub_rn(dnk, sh.front(dq)))) ++dq;
                 e_fire = (unsigned)dq * 16u;
-                atomicMin(tb.quiet(j), (int)e_fire);
+                atomicMin(tb.quiet(j - j_lo), (int)e_fire);
                 // an interval whose end precedes its start could trade a large "behind"
                 // constant for a small front term
-                if (ck != 0.0) atomicOr(tb.quiet(j) + 1, 1);
+                if (ck != 0.0) atomicOr(tb.quiet(j - j_lo) + 1, 1);
             }
         }
         rec[2 * k] = dnk;
@@ -337,13 +381,14 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // wave's position in the workgroup also fixes the SIMD it runs on, so a fixed direction
     // would hand the longest cells of every pass to the same SIMD
     bool flip = false;
-    for (int jb = 0; jb < n_s; jb += G, flip = !flip) {
-        const int j = n_s - 1 - (jb + (flip ? G - 1 - g : g));
-        const bool live = j >= 0;
+    const double u_cap = rg.u_cap;
+    for (int jb = 0; jb < n_c; jb += G, flip = !flip) {
+        const int j = rg.j_hi - (jb + (flip ? G - 1 - g : g));
+        const bool live = j >= j_lo;
         double best = MP_INF;
         int bp = 0x7fffffff;
         if (live) {
-            const double *rec = tb.cell(j);
+            const double *rec = tb.cell(j - j_lo);
             double dn[RT > 0 ? RT : 1], cst[RT > 0 ? RT : 1];
             unsigned fire[(RT + 1) / 2 > 0 ? (RT + 1) / 2 : 1];
 #pragma unroll
@@ -395,8 +440,12 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                     }
                 }
                 const double base = __dadd_rn(obv, fsv.y);
-                if constexpr (!FIRST)
-                    if (e >= e_brk && __dadd_rn(base, m_prev) > best) { ST_CNT_LANE(4); return true; }
+                if constexpr (!FIRST) {
+                    // (capped: what is left costs more than the lane's best or more than the
+                    // plan can cost in the end; either way it cannot matter)
+                    const double bound = CAPPED ? (best < u_cap ? best : u_cap) : best;
+                    if (e >= e_brk && __dadd_rn(base, m_prev) > bound) { ST_CNT_LANE(4); return true; }
+                }
                 // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
                 const double2 chv = *(const double2 *)(ch_j - e);
                 const int h = __double2loint(chv.y);
@@ -415,8 +464,15 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 if (FIRST || c <= best) { best = c; be = e; }
                 return false;
             };
+            // Capped: a cell whose constants alone (the intervals it is inside of or has just
+            // passed; where no interval trades its constant for a front term, the obstacle sum
+            // of any edge into the cell is at least their sum) put it above the bound is not
+            // priced at all: it keeps an infinite cost and itself as predecessor.
+            const bool dead = CAPPED && RT > 0 && qf.y == 0 && __dadd_rn(ob_quiet, m_prev) > u_cap;
             int e = r * 16;
-            if (e <= ej) {
+            if (dead) {
+                be = 0;
+            } else if (e <= ej) {
                 step(e, std::true_type());
                 for (e += 16 * ST_SPLIT; e <= ej; e += 16 * ST_SPLIT)
                     if (step(e, std::false_type())) break;
@@ -428,7 +484,11 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
         if (live && r == 0) {
             sh.cost_cur(j) = best;
             sh.pre16[(size_t)i * N + j] = (short)bp;
-            st_store_hist(sh, i, N, j, bp);
+            const int hist = st_store_hist(sh, i, N, j, bp);
+            if (rg.keep_cost) {
+                rg.keep_cost[j] = best;
+                rg.keep_hist[j] = hist;
+            }
             if (cost_g) cost_g[(size_t)i * N + j] = best;
             if (pre_g) pre_g[(size_t)i * N + j] = bp;
             m_loc = best < m_loc ? best : m_loc;
@@ -529,7 +589,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     }
     if (tid == 0) last_col[0] = 0.0;
     // quiet and flag word of every cell record at their reset values (whoever reads them puts them back)
-    for (int j = tid; j < n_s; j += nt) {
+    for (int j = tid; j < min(n_s, st_rec_cells(N, a.k_prefix)); j += nt) {
         tb.quiet(j)[0] = 0x7fffffff;
         tb.quiet(j)[1] = 0;
     }
@@ -543,103 +603,159 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     }
     __syncthreads();
     const int d_lim = *d_lim_sh;
-    double m_prev = 0.0; // minimum of cost_prev
 
-    // the interval count of a layer is fetched while the layer before it is relaxed
-    int R_next = min(max(a.n_reg[(size_t)b * n_t + 1], 0), R_max);
-    for (int i = 1; i < n_t; ++i) {
-        const int R = R_next;
-        const bool staged = R <= pitch; // else: in global memory
-        sh.down = down_all + i * pitch;
-        sh.up = up_all + i * pitch;
-        const double *g_down = a.s_down + ((size_t)b * n_t + i) * R_max, *g_up = a.s_up + ((size_t)b * n_t + i) * R_max;
-        if (i + 1 < n_t) R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
-        double m_loc = MP_INF;
-        if (i == 1) {
-            // only p_j = 0 (speed_planner.py:96-100)
-            for (int j = tid; j < n_s; j += nt) {
-                const double s = __dmul_rn((double)j, ds);
-                double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)j), ds), dt);
-                double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
-                double jk = __ddiv_rn(ac, dt);
-                StCellLds cell;
-                double ob;
-                if (staged) {
-                    cell.init(s, sh.down, sh.up, R);
-                    ob = cell.ob(s, sh.front(j));
-                } else {
-                    cell.init(s, g_down, g_up, R);
-                    ob = cell.ob(s, sh.front(j));
+    // One sweep over the time layers for the cells rg.j_lo..rg.j_hi.  Cell j only looks at cells
+    // 0..j of the layer before, so the cells 0..k can be planned through all layers on their own
+    // (first sweep: their costs and history words of every layer are kept), and the cheapest of
+    // them in the last layer bounds the plan's final cost from above: the end state is the
+    // cheaper of the cheapest cell of the last layer and the cheapest last cell of any layer, so
+    // it costs at most u.  Costs never decrease along a chain of predecessors (every term of an
+    // edge is >= 0 and rounding is monotone), so a cell that costs more than u is neither on the
+    // plan nor the predecessor that decides any cell of it; the second sweep (cells k+1.., with
+    // row i-1 of the first sweep's cells copied in beside its own) therefore stops a walk as soon
+    // as everything left of it is certain to cost more than min(lane's best, u).  Cells that
+    // cost at most u come out exactly as without the bound (costs and predecessors), cells
+    // above it with some value above it, and the end state and its chain are the same.  Most of a
+    // grid is such cells (far ahead, behind obstacles), and their walks were the long ones.
+    auto sweep = [&](const StRange &rg0, auto capped_tag, bool second, double *keep_c, int *keep_h, int kA,
+                     double *m_keep) -> double {
+        constexpr bool CAPPED = decltype(capped_tag)::value;
+        double m_prev = 0.0; // minimum of cost_prev
+        // the interval count of a layer is fetched while the layer before it is relaxed
+        int R_next = min(max(a.n_reg[(size_t)b * n_t + 1], 0), R_max);
+        for (int i = 1; i < n_t; ++i) {
+            const int R = R_next;
+            const bool staged = R <= pitch; // else: in global memory
+            sh.down = down_all + i * pitch;
+            sh.up = up_all + i * pitch;
+            const double *g_down = a.s_down + ((size_t)b * n_t + i) * R_max, *g_up = a.s_up + ((size_t)b * n_t + i) * R_max;
+            if (i + 1 < n_t) R_next = min(max(a.n_reg[(size_t)b * n_t + i + 1], 0), R_max);
+            StRange rg = rg0;
+            if (keep_c && !second) { // first sweep: this layer's row of the kept costs
+                rg.keep_cost = keep_c + (size_t)i * kA;
+                rg.keep_hist = keep_h + (size_t)i * kA;
+            }
+            double m_loc = MP_INF;
+            if (i == 1) {
+                // only p_j = 0 (speed_planner.py:96-100)
+                for (int j = rg.j_lo + tid; j <= rg.j_hi; j += nt) {
+                    const double s = __dmul_rn((double)j, ds);
+                    double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)j), ds), dt);
+                    double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
+                    double jk = __ddiv_rn(ac, dt);
+                    StCellLds cell;
+                    double ob;
+                    if (staged) {
+                        cell.init(s, sh.down, sh.up, R);
+                        ob = cell.ob(s, sh.front(j));
+                    } else {
+                        cell.init(s, g_down, g_up, R);
+                        ob = cell.ob(s, sh.front(j));
+                    }
+                    double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed(j)), __dmul_rn(__dmul_rn(ac, ac), dt)),
+                                            __dmul_rn(__dmul_rn(jk, jk), dt));
+                    sh.cost_cur(j) = best;
+                    sh.pre16[(size_t)i * N + j] = 0;
+                    const int hist = st_store_hist(sh, i, N, j, 0);
+                    if (rg.keep_cost) {
+                        rg.keep_cost[j] = best;
+                        rg.keep_hist[j] = hist;
+                    }
+                    if (cost_g) cost_g[(size_t)i * N + j] = best;
+                    if (pre_g) pre_g[(size_t)i * N + j] = 0;
+                    m_loc = best < m_loc ? best : m_loc;
                 }
-                double best = __dadd_rn(__dadd_rn(__dadd_rn(ob, sh.speed(j)), __dmul_rn(__dmul_rn(ac, ac), dt)),
-                                        __dmul_rn(__dmul_rn(jk, jk), dt));
-                sh.cost_cur(j) = best;
-                sh.pre16[(size_t)i * N + j] = 0;
-                st_store_hist(sh, i, N, j, 0);
-                if (cost_g) cost_g[(size_t)i * N + j] = best;
-                if (pre_g) pre_g[(size_t)i * N + j] = 0;
-                m_loc = best < m_loc ? best : m_loc;
-            }
-        } else if (RTK >= 0) {
-            if constexpr (RTK >= 0) {
-                if (R <= RTK && RTK <= a.r_tab && staged)
-                    m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
-                else if (staged)
-                    m_loc = st_relax_layer<StCellLds>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
-                else
-                    m_loc = st_relax_layer<StCellLds>(a, sh, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
-            }
-        } else if (R <= 8 && (R == 7 ? 8 : R) <= a.r_tab && staged) { // 7 intervals run as 8 with one padded slot
+            } else if (RTK >= 0) {
+                if constexpr (RTK >= 0) {
+                    if (R <= RTK && RTK <= a.r_tab && staged)
+                        m_loc = st_relax_layer_split<RTK, SPLITK, CAPPED>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                    else if (staged)
+                        m_loc = st_relax_layer<StCellLds>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                    else
+                        m_loc = st_relax_layer<StCellLds>(a, sh, rg, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                }
+            } else if (R <= 8 && (R == 7 ? 8 : R) <= a.r_tab && staged) { // 7 intervals run as 8 with one padded slot
 #define ST_SPLIT_CASE(RT)                                                                                   \
-    m_loc = a.lanes_per_cell == 4 ? st_relax_layer_split<RT, 4>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
-                    : st_relax_layer_split<RT, 8>(a, sh, tb, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
-            switch (R) {
-            case 0: ST_SPLIT_CASE(0); break;
-            case 1: ST_SPLIT_CASE(1); break;
-            case 2: ST_SPLIT_CASE(2); break;
-            case 3: ST_SPLIT_CASE(3); break;
-            case 4: ST_SPLIT_CASE(4); break;
-            case 5: ST_SPLIT_CASE(5); break;
-            case 6: ST_SPLIT_CASE(6); break;
-            default: ST_SPLIT_CASE(8); break;
-            }
+    m_loc = a.lanes_per_cell == 4 ? st_relax_layer_split<RT, 4>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)   \
+                    : st_relax_layer_split<RT, 8>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g)
+                switch (R) {
+                case 0: ST_SPLIT_CASE(0); break;
+                case 1: ST_SPLIT_CASE(1); break;
+                case 2: ST_SPLIT_CASE(2); break;
+                case 3: ST_SPLIT_CASE(3); break;
+                case 4: ST_SPLIT_CASE(4); break;
+                case 5: ST_SPLIT_CASE(5); break;
+                case 6: ST_SPLIT_CASE(6); break;
+                default: ST_SPLIT_CASE(8); break;
+                }
 #undef ST_SPLIT_CASE
-        } else if (!staged) {
-            m_loc = st_relax_layer<StCellLds>(a, sh, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
-        } else {
-            switch (R) {
-            case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 1: m_loc = st_relax_layer<StCell<1>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 2: m_loc = st_relax_layer<StCell<2>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 3: m_loc = st_relax_layer<StCell<3>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 4: m_loc = st_relax_layer<StCell<4>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 5: m_loc = st_relax_layer<StCell<5>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 6: m_loc = st_relax_layer<StCell<6>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            case 7:
-            case 8: m_loc = st_relax_layer<StCell<8>>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
-            default: m_loc = st_relax_layer<StCellLds>(a, sh, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+            } else if (!staged) {
+                m_loc = st_relax_layer<StCellLds>(a, sh, rg, g_down, g_up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+            } else {
+                switch (R) {
+                case 0: m_loc = st_relax_layer<StCell<0>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 1: m_loc = st_relax_layer<StCell<1>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 2: m_loc = st_relax_layer<StCell<2>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 3: m_loc = st_relax_layer<StCell<3>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 4: m_loc = st_relax_layer<StCell<4>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 5: m_loc = st_relax_layer<StCell<5>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 6: m_loc = st_relax_layer<StCell<6>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                case 7:
+                case 8: m_loc = st_relax_layer<StCell<8>>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                default: m_loc = st_relax_layer<StCellLds>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g); break;
+                }
             }
+            // padding cells keep the initial values
+            for (int j = n_s + tid; j < N; j += nt) {
+                if (cost_g) cost_g[(size_t)i * N + j] = 0.0;
+                if (pre_g) pre_g[(size_t)i * N + j] = -1;
+            }
+            // second sweep: the first sweep's cells of this layer beside the cells just relaxed, so
+            // that the row is whole for the next layer (and, after the last one, for the end state)
+            if (second)
+                for (int j = tid; j < kA; j += nt) {
+                    sh.cost_cur(j) = keep_c[(size_t)i * kA + j];
+                    *(int *)(sh.ch_cur + 2 * j + 1) = keep_h[(size_t)i * kA + j];
+                }
+            // (a layer that takes the thread-per-cell relaxation has no barrier of its own: a wave
+            // may be writing the next layer's minimum while another still reads this one's, hence
+            // the two buffers)
+            double *red_i = red + 8 * (i & 1);
+            m_loc = wave_min_f64(m_loc);
+            if ((tid & (MP_WAVE - 1)) == 0) red_i[wave] = m_loc;
+            __syncthreads();
+            if (tid == 0 && rg.j_hi == n_s - 1) last_col[i] = sh.cost_cur(n_s - 1);
+            m_prev = red_i[0];
+            for (int w = 1; w < nw; ++w) m_prev = red_i[w] < m_prev ? red_i[w] : m_prev;
+            if (m_keep) {
+                // the whole row's minimum: the first sweep leaves its own per layer, the second joins them
+                if (second) m_prev = m_keep[i] < m_prev ? m_keep[i] : m_prev;
+                else if (tid == 0) m_keep[i] = m_prev;
+            }
+            // the two cost rows swap roles: the next layer writes the row this one read
+            double *row = sh.ch_prev;
+            sh.ch_prev = sh.ch_cur;
+            sh.ch_cur = row;
         }
-        // padding cells keep the initial values
-        for (int j = n_s + tid; j < N; j += nt) {
-            if (cost_g) cost_g[(size_t)i * N + j] = 0.0;
-            if (pre_g) pre_g[(size_t)i * N + j] = -1;
-        }
-        // (a layer that takes the thread-per-cell relaxation has no barrier of its own: a wave
-        // may be writing the next layer's minimum while another still reads this one's, hence
-        // the two buffers)
-        double *red_i = red + 8 * (i & 1);
-        m_loc = wave_min_f64(m_loc);
-        if ((tid & (MP_WAVE - 1)) == 0) red_i[wave] = m_loc;
-        __syncthreads();
-        if (tid == 0) last_col[i] = sh.cost_cur(n_s - 1);
-        m_prev = red_i[0];
-        for (int w = 1; w < nw; ++w) m_prev = red_i[w] < m_prev ? red_i[w] : m_prev;
-        // the two cost rows swap roles: the next layer writes the row this one read
-        double *row = sh.ch_prev;
-        sh.ch_prev = sh.ch_cur;
-        sh.ch_cur = row;
+        return m_prev;
+    };
+
+    const StRange whole{0, n_s - 1, MP_INF, nullptr, nullptr};
+    const int kA = a.k_prefix + 1; // cells of the first sweep
+    bool two_sweeps = false;
+    if constexpr (RTK >= 0 && !TABLES) two_sweeps = a.k_prefix > 0 && n_s > kA;
+    if constexpr (RTK >= 0 && !TABLES) if (two_sweeps) {
+        // (kept rows: behind the cell records; see st_keep_offset)
+        double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.k_prefix) / 8;
+        double *m_keep = keep_c + (size_t)n_t * kA;
+        int *keep_h = (int *)(m_keep + n_t);
+        const StRange first{0, kA - 1, MP_INF, nullptr, nullptr};
+        const double u = sweep(first, std::false_type(), false, keep_c, keep_h, kA, m_keep);
+        __syncthreads(); // the first sweep is done with the rows and the minimum buffers
+        const StRange rest{kA, n_s - 1, u, nullptr, nullptr};
+        sweep(rest, std::true_type(), true, keep_c, keep_h, kA, m_keep);
     }
+    if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, nullptr, 0, nullptr);
     __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
@@ -1032,14 +1148,27 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // the 8 the lanes-per-cell relaxation takes; a layer with more is read from global memory
     const int r_slots_1 = r_max > 0 ? r_max : 1;
     const int r_pitch = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024 ? r_slots_1 : 8;
-    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    // the instances for large batches plan the cells a vehicle within the speed limit can reach
+    // first (see st_dp_body): cells 0..k, k = (cells per layer at the first speed above the
+    // limit) x (layers)
+    int rk = r_max == 7 ? 8 : r_max;
+    if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() <= 0) || cost || pre) rk = -1;
+    int k_prefix = 0;
+    if (rk >= 0 && n_t >= 3) {
+        int d_over = 0;
+        while (d_over < n_s_max && !(1.0 * d_over * ds / dt > speed_lim)) ++d_over;
+        int k = d_over * (n_t - 1);
+        if (mp_knob_st_prefix() >= 0) k = mp_knob_st_prefix(); // tests: 0 = one sweep
+        if (k > 0 && k + 8 < n_s_max) k_prefix = k;
+    }
+    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, k_prefix, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_tab_offset(n_s_max, r_pitch * n_t, n_t) + st_tab_bytes(n_s_max, r_tab);
+    size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, k_prefix) + st_keep_bytes(n_t, k_prefix);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
@@ -1053,8 +1182,6 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // large batches with few intervals per layer (r_max is the caller's bound) take the
     // instance built for that bound and grid width class; MP_ST_GENERIC=1 keeps them on the
     // kernel that holds every path
-    int rk = r_max == 7 ? 8 : r_max;
-    if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() <= 0)) rk = -1;
 #define ST_R_LAUNCH(RT)                                                                      \
     if (a.lanes_per_cell == 4) hipLaunchKernelGGL((st_dp_r_kernel<RT, 4>), grid, block, lds, st, a); \
     else hipLaunchKernelGGL((st_dp_r_kernel<RT, 8>), grid, block, lds, st, a)
