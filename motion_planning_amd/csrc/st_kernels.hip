@@ -187,6 +187,7 @@ __device__ __forceinline__ int st_store_hist(const StSh &sh, int i, int N, int j
 // not be priced (see st_dp_body).  keep_cost / keep_hist (may be null): where the cells' costs
 // and history words of this layer are kept beside the cost row, indexed by cell.
 struct StRange {
+    int n_s; // cells of the scenario's grid
     int j_lo, j_hi;
     double u_cap;
     double *keep_cost;
@@ -255,6 +256,63 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
     return m_loc;
 }
 
+// The cells j_lo..j_hi of a layer when a bound u_cap on the plan's final cost is known (the
+// second sweep of st_dp_body), one thread per cell.  Nearly all of these cells lie far ahead or
+// behind an obstacle and cost more than the bound whatever their predecessor: the constants of
+// the intervals a cell is inside of or has just passed are part of every edge into it (where no
+// interval trades its constant for a front term), so if their in-order sum plus the cheapest
+// cell of the layer before already exceeds the bound the cell keeps an infinite cost and itself
+// as predecessor, unpriced.  The few others are walked as st_relax_layer walks them, with the
+// bound in the stop test.
+template <int RT>
+__device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const StSh &sh, const StRange &rg,
+                                                        int i, int N, int R, int d_lim, double m_prev)
+{
+    const double ds = a.ds, u_cap = rg.u_cap;
+    const int n_s1 = rg.n_s - 1;
+    const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
+    const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
+    double m_loc = MP_INF;
+    for (int j = rg.j_lo + threadIdx.x; j <= rg.j_hi; j += blockDim.x) {
+        const double s = __dmul_rn((double)j, ds);
+        StCell<RT> cell;
+        cell.init(s, sh.down, sh.up, R);
+        double ob_quiet = 0.0;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) ob_quiet = (k == 0) ? cell.cst[0] : __dadd_rn(ob_quiet, cell.cst[k]);
+        double best = MP_INF;
+        int bp = j;
+        if (!(cell.monotone && __dadd_rn(ob_quiet, m_prev) > u_cap)) {
+            bool first = true;
+            for (int p = j; p >= 0; --p) {
+                const int d = j - p;
+                const double cp = sh.cost_prev(p);
+                const double base = __dadd_rn(cell.ob(s, sh.front(d)), sh.speed(d));
+                if (!first && cell.monotone && d >= d_lim &&
+                    __dadd_rn(base, m_prev) > (best < u_cap ? best : u_cap))
+                    break;
+                const int pp = pre1[p];
+                const int n = d - (p - pp);
+                double jc;
+                if (i == 2) jc = sh.jerk2[n + n_s1];
+                else {
+                    const int ppp = pre2[pp];
+                    jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * n_s1];
+                }
+                const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n_s1]), jc);
+                const double c = __dadd_rn(tot, cp);
+                if (first || c <= best) { best = c; bp = p; } // lower index wins ties
+                first = false;
+            }
+        }
+        sh.cost_cur(j) = best;
+        sh.pre16[(size_t)i * N + j] = (short)bp;
+        st_store_hist(sh, i, N, j, bp);
+        m_loc = best < m_loc ? best : m_loc;
+    }
+    return m_loc;
+}
+
 // Per-cell interval records in LDS, one per cell: r_tab pairs (dn, cst); then two ints: 16
 // times the smallest predecessor distance at which any interval takes the front formula,
 // and a word that is non-zero when the cell's obstacle cost is not monotone in the edge
@@ -280,13 +338,12 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 {
     return (size_t)N * st_rec_stride(r_tab) * sizeof(double);
 }
-// Cells the records are laid out for: the whole grid, or the larger of the two sweeps' shares
-// (cells 0..k_prefix, then the rest; see st_dp_body).
+// Cells the records are laid out for: the whole grid, or the first sweep's cells 0..k_prefix (the
+// second sweep keeps a cell's intervals in registers; a scenario of such a launch whose grid is
+// no wider than that is planned in one sweep; see st_dp_body).
 __host__ __device__ __forceinline__ int st_rec_cells(int N, int k_prefix)
 {
-    if (k_prefix <= 0) return N;
-    const int first = k_prefix + 1, rest = N - first;
-    return first > rest ? first : rest;
+    return k_prefix <= 0 ? N : k_prefix + 1;
 }
 // Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
 // layers' minima over them (double [n_t]) and their history words (int [n_t][k+1]).
@@ -322,9 +379,8 @@ __host__ __device__ __forceinline__ size_t st_keep_bytes(int n_t, int k_prefix)
 // walks short (three or four steps per lane on a 97-cell grid), so what a pass over the
 // cells costs outside the walk matters as much as the walk: a cell's intervals, fire
 // distances and flags are one record, read with constant offsets from one address.
-// CAPPED: rg.u_cap bounds the plan's final cost, and a walk also stops once everything left
-// of it is certain to cost more than that.  Records are indexed from the range's first cell.
-template <int RT, int ST_SPLIT, bool CAPPED = false>
+// Records are indexed from the range's first cell.
+template <int RT, int ST_SPLIT>
 __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StSh &sh, const StTab &tb,
                                                        const StRange &rg, int i,
                                                        int n_s, int N, int R, int d_lim, double m_prev,
@@ -381,7 +437,6 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
     // wave's position in the workgroup also fixes the SIMD it runs on, so a fixed direction
     // would hand the longest cells of every pass to the same SIMD
     bool flip = false;
-    const double u_cap = rg.u_cap;
     for (int jb = 0; jb < n_c; jb += G, flip = !flip) {
         const int j = rg.j_hi - (jb + (flip ? G - 1 - g : g));
         const bool live = j >= j_lo;
@@ -440,12 +495,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                     }
                 }
                 const double base = __dadd_rn(obv, fsv.y);
-                if constexpr (!FIRST) {
-                    // (capped: what is left costs more than the lane's best or more than the
-                    // plan can cost in the end; either way it cannot matter)
-                    const double bound = CAPPED ? (best < u_cap ? best : u_cap) : best;
-                    if (e >= e_brk && __dadd_rn(base, m_prev) > bound) { ST_CNT_LANE(4); return true; }
-                }
+                if constexpr (!FIRST)
+                    if (e >= e_brk && __dadd_rn(base, m_prev) > best) { ST_CNT_LANE(4); return true; }
                 // acceleration on j - 2p + pp, jerk on j - 3p + 3pp - ppp (speed_planner.py:124-136)
                 const double2 chv = *(const double2 *)(ch_j - e);
                 const int h = __double2loint(chv.y);
@@ -464,15 +515,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
                 if (FIRST || c <= best) { best = c; be = e; }
                 return false;
             };
-            // Capped: a cell whose constants alone (the intervals it is inside of or has just
-            // passed; where no interval trades its constant for a front term, the obstacle sum
-            // of any edge into the cell is at least their sum) put it above the bound is not
-            // priced at all: it keeps an infinite cost and itself as predecessor.
-            const bool dead = CAPPED && RT > 0 && qf.y == 0 && __dadd_rn(ob_quiet, m_prev) > u_cap;
             int e = r * 16;
-            if (dead) {
-                be = 0;
-            } else if (e <= ej) {
+            if (e <= ej) {
                 step(e, std::true_type());
                 for (e += 16 * ST_SPLIT; e <= ej; e += 16 * ST_SPLIT)
                     if (step(e, std::false_type())) break;
@@ -667,8 +711,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                 }
             } else if (RTK >= 0) {
                 if constexpr (RTK >= 0) {
-                    if (R <= RTK && RTK <= a.r_tab && staged)
-                        m_loc = st_relax_layer_split<RTK, SPLITK, CAPPED>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
+                    if (CAPPED && R <= RTK && staged)
+                        m_loc = st_relax_layer_capped<RTK>(a, sh, rg, i, N, R, d_lim, m_prev);
+                    else if (R <= RTK && RTK <= a.r_tab && staged)
+                        m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
                     else if (staged)
                         m_loc = st_relax_layer<StCellLds>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
                     else
@@ -740,7 +786,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         return m_prev;
     };
 
-    const StRange whole{0, n_s - 1, MP_INF, nullptr, nullptr};
+    const StRange whole{n_s, 0, n_s - 1, MP_INF, nullptr, nullptr};
     const int kA = a.k_prefix + 1; // cells of the first sweep
     bool two_sweeps = false;
     if constexpr (RTK >= 0 && !TABLES) two_sweeps = a.k_prefix > 0 && n_s > kA;
@@ -749,10 +795,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.k_prefix) / 8;
         double *m_keep = keep_c + (size_t)n_t * kA;
         int *keep_h = (int *)(m_keep + n_t);
-        const StRange first{0, kA - 1, MP_INF, nullptr, nullptr};
+        const StRange first{n_s, 0, kA - 1, MP_INF, nullptr, nullptr};
         const double u = sweep(first, std::false_type(), false, keep_c, keep_h, kA, m_keep);
         __syncthreads(); // the first sweep is done with the rows and the minimum buffers
-        const StRange rest{kA, n_s - 1, u, nullptr, nullptr};
+        const StRange rest{n_s, kA, n_s - 1, u, nullptr, nullptr};
         sweep(rest, std::true_type(), true, keep_c, keep_h, kA, m_keep);
     }
     if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, nullptr, 0, nullptr);
