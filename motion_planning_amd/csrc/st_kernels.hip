@@ -20,7 +20,8 @@
 // Development aid, built only with -DST_COUNT (tools/count_st.py): what the walks of the
 // split relaxation do.  0 wave steps, 1 lane steps (edges priced), 2 wave steps that took
 // the quiet obstacle sum, 4 lanes stopped by the bound, 5 wave passes, 8 first wave steps,
-// 9 / 10 later lane steps that did / did not improve the lane's best.
+// 9 / 10 later lane steps that did / did not improve the lane's best; 11 / 12 cells of a second
+// sweep that were not priced / all of them (their priced edges count as lane steps too).
 __device__ unsigned long long st_cnt[16];
 #define ST_CNT_WAVE(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&st_cnt[i], 1ull); } while (0)
 #define ST_CNT_LANE(i) atomicAdd(&st_cnt[i], 1ull)
@@ -43,6 +44,7 @@ struct StDev {
     int32_t lanes_per_cell;             // 4 or 8 (st_lanes_per_cell)
     int32_t r_pitch;                    // interval slots per time layer in LDS (layers with more are read from global memory)
     int32_t k_prefix;                   // > 0: cells 0..k_prefix are planned first, for a bound on the plan's cost (see st_dp_body)
+    int32_t rec_cells;                  // cells the LDS cell records are laid out for (n_s_max, or k_prefix + 1)
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -95,6 +97,16 @@ struct StCell {
         }
     }
 
+    // in-order sum of the constants: what the obstacle terms of an edge into the cell add up to
+    // at least, if the cell is monotone (padding adds exact zeros)
+    __device__ __forceinline__ double quiet(double) const
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) acc = (k == 0) ? cst[0] : __dadd_rn(acc, cst[k]);
+        return acc;
+    }
+
     __device__ __forceinline__ double ob(double s, double front) const
     {
         const double fs = __dadd_rn(front, s);
@@ -123,6 +135,16 @@ struct StCellLds {
             StCell<1>::classify(s, down[k], up[k], &dnk, &c);
             if (dnk != MP_INF && c != 0.0) monotone = false;
         }
+    }
+    __device__ __forceinline__ double quiet(double s) const
+    {
+        double acc = 0.0;
+        for (int k = 0; k < R; ++k) {
+            double dnk, c;
+            StCell<1>::classify(s, down[k], up[k], &dnk, &c);
+            acc = __dadd_rn(acc, c);
+        }
+        return acc;
     }
     __device__ __forceinline__ double ob(double s, double front) const
     {
@@ -186,6 +208,9 @@ __device__ __forceinline__ int st_store_hist(const StSh &sh, int i, int N, int j
 // cost cannot exceed (MP_INF: none known); a candidate whose cost is certain to exceed it need
 // not be priced (see st_dp_body).  keep_cost / keep_hist (may be null): where the cells' costs
 // and history words of this layer are kept beside the cost row, indexed by cell.
+#ifndef ST_TWO_SWEEP_REGS
+#define ST_TWO_SWEEP_REGS 2 // intervals per layer, on average, from which a grid is planned in two sweeps
+#endif
 struct StRange {
     int n_s; // cells of the scenario's grid
     int j_lo, j_hi;
@@ -262,35 +287,41 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
 // the intervals a cell is inside of or has just passed are part of every edge into it (where no
 // interval trades its constant for a front term), so if their in-order sum plus the cheapest
 // cell of the layer before already exceeds the bound the cell keeps an infinite cost and itself
-// as predecessor, unpriced.  The few others are walked as st_relax_layer walks them, with the
-// bound in the stop test.
-template <int RT>
+// as predecessor, unpriced.  The others are walked as st_relax_layer walks them, with the bound
+// in the stop and skip tests, and from the last cell of the layer before that costs no more than
+// the bound (reach[i - 1]; a predecessor above the bound decides nothing): a cell far ahead of
+// it starts at a speed whose cost alone ends the walk at once.  reach[i] takes the cells of this
+// layer within the bound.
+template <class CELL>
 __device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const StSh &sh, const StRange &rg,
-                                                        int i, int N, int R, int d_lim, double m_prev)
+                                                        const double *down, const double *up, int i, int N, int R,
+                                                        int d_lim, double m_prev, int *reach)
 {
     const double ds = a.ds, u_cap = rg.u_cap;
     const int n_s1 = rg.n_s - 1;
     const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
     const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
+    const int j_reach = reach[i - 1] >= 0 ? reach[i - 1] : N;
     double m_loc = MP_INF;
     for (int j = rg.j_lo + threadIdx.x; j <= rg.j_hi; j += blockDim.x) {
         const double s = __dmul_rn((double)j, ds);
-        StCell<RT> cell;
-        cell.init(s, sh.down, sh.up, R);
-        double ob_quiet = 0.0;
-#pragma unroll
-        for (int k = 0; k < RT; ++k) ob_quiet = (k == 0) ? cell.cst[0] : __dadd_rn(ob_quiet, cell.cst[k]);
+        CELL cell;
+        cell.init(s, down, up, R);
+        const double ob_quiet = cell.quiet(s);
         double best = MP_INF;
         int bp = j;
-        if (!(cell.monotone && __dadd_rn(ob_quiet, m_prev) > u_cap)) {
-            bool first = true;
-            for (int p = j; p >= 0; --p) {
+        ST_CNT_LANE(12);
+        if (cell.monotone && __dadd_rn(ob_quiet, m_prev) > u_cap) {
+            ST_CNT_LANE(11);
+        } else {
+            for (int p = min(j, j_reach); p >= 0; --p) {
                 const int d = j - p;
                 const double cp = sh.cost_prev(p);
                 const double base = __dadd_rn(cell.ob(s, sh.front(d)), sh.speed(d));
-                if (!first && cell.monotone && d >= d_lim &&
-                    __dadd_rn(base, m_prev) > (best < u_cap ? best : u_cap))
-                    break;
+                const double cap = best < u_cap ? best : u_cap;
+                if (cell.monotone && d >= d_lim && __dadd_rn(base, m_prev) > cap) break;
+                if (__dadd_rn(base, cp) > cap) continue;
+                ST_CNT_LANE(1);
                 const int pp = pre1[p];
                 const int n = d - (p - pp);
                 double jc;
@@ -301,10 +332,10 @@ __device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const St
                 }
                 const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n_s1]), jc);
                 const double c = __dadd_rn(tot, cp);
-                if (first || c <= best) { best = c; bp = p; } // lower index wins ties
-                first = false;
+                if (c <= best) { best = c; bp = p; } // lower index wins ties
             }
         }
+        if (best <= u_cap) atomicMax(reach + i, j);
         sh.cost_cur(j) = best;
         sh.pre16[(size_t)i * N + j] = (short)bp;
         st_store_hist(sh, i, N, j, bp);
@@ -338,25 +369,23 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 {
     return (size_t)N * st_rec_stride(r_tab) * sizeof(double);
 }
-// Cells the records are laid out for: the whole grid, or the first sweep's cells 0..k_prefix (the
-// second sweep keeps a cell's intervals in registers; a scenario of such a launch whose grid is
-// no wider than that is planned in one sweep; see st_dp_body).
-__host__ __device__ __forceinline__ int st_rec_cells(int N, int k_prefix)
-{
-    return k_prefix <= 0 ? N : k_prefix + 1;
-}
+// (StDev.rec_cells: the cells the records are laid out for: the whole grid, or, in the instances
+// for large batches, the first sweep's cells 0..k_prefix only: the second sweep keeps a cell's
+// intervals in registers, and a scenario of such a launch that is planned in one sweep has the
+// kept rows' room behind the records for its other cells; see st_dp_body.)
 // Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
-// layers' minima over them (double [n_t]) and their history words (int [n_t][k+1]).
-__host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int k_prefix)
+// layers' minima over them (double [n_t]), their history words (int [n_t][k+1]) and, per layer, the
+// last cell that costs no more than the bound (int [n_t]).
+__host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int rec_cells)
 {
-    const size_t b = st_tab_offset(N, r_slots, n_t) + st_tab_bytes(st_rec_cells(N, k_prefix), r_tab);
+    const size_t b = st_tab_offset(N, r_slots, n_t) + st_tab_bytes(rec_cells, r_tab);
     return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ __forceinline__ size_t st_keep_bytes(int n_t, int k_prefix)
 {
     if (k_prefix <= 0) return 0;
     const size_t cells = (size_t)n_t * (k_prefix + 1);
-    return (cells + n_t) * sizeof(double) + cells * sizeof(int);
+    return (cells + n_t) * sizeof(double) + (cells + n_t) * sizeof(int);
 }
 
 // All cells of time layer i >= 2, ST_SPLIT lanes per cell.
@@ -632,8 +661,30 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         if (pre_g) pre_g[j] = -1;
     }
     if (tid == 0) last_col[0] = 0.0;
+    // Two sweeps (see below) pay when the first covers less than half of the grid; a narrower grid
+    // is planned in one, its cell records running on into the room of the first sweep's kept rows
+    // where that is needed (and as far as that room goes).
+    const int kA = a.k_prefix + 1; // cells of the first sweep
+    bool two_sweeps = false;
+    if constexpr (!TABLES)
+        if (a.k_prefix > 0) {
+            const int room = a.rec_cells >= N ? N
+                           : (int)((st_tab_bytes(a.rec_cells, a.r_tab) + st_keep_bytes(n_t, a.k_prefix)) /
+                                   (st_rec_stride(a.r_tab) * sizeof(double)));
+            two_sweeps = n_s > min(2 * kA - 1, room);
+            // ... and when the cells beyond the first sweep are dear ones: a cell inside an interval
+            // or up to 25 m past one carries a constant far above any plan's cost, which no walk of
+            // the one sweep can prune against (its own best holds that constant too); a grid with few
+            // intervals has few such cells.  (A grid wider than the records have room for takes two
+            // sweeps in any case.)
+            if (two_sweeps && n_s <= room) {
+                int regs = 0;
+                for (int i = 1; i < n_t; ++i) regs += a.n_reg[(size_t)b * n_t + i];
+                two_sweeps = regs >= ST_TWO_SWEEP_REGS * (n_t - 1);
+            }
+        }
     // quiet and flag word of every cell record at their reset values (whoever reads them puts them back)
-    for (int j = tid; j < min(n_s, st_rec_cells(N, a.k_prefix)); j += nt) {
+    for (int j = tid; j < (two_sweeps ? kA : n_s); j += nt) {
         tb.quiet(j)[0] = 0x7fffffff;
         tb.quiet(j)[1] = 0;
     }
@@ -662,7 +713,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     // above it with some value above it, and the end state and its chain are the same.  Most of a
     // grid is such cells (far ahead, behind obstacles), and their walks were the long ones.
     auto sweep = [&](const StRange &rg0, auto capped_tag, bool second, double *keep_c, int *keep_h, int kA,
-                     double *m_keep) -> double {
+                     double *m_keep, int *reach) -> double {
         constexpr bool CAPPED = decltype(capped_tag)::value;
         double m_prev = 0.0; // minimum of cost_prev
         // the interval count of a layer is fetched while the layer before it is relaxed
@@ -707,13 +758,24 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                     }
                     if (cost_g) cost_g[(size_t)i * N + j] = best;
                     if (pre_g) pre_g[(size_t)i * N + j] = 0;
+                    if constexpr (CAPPED)
+                        if (best <= rg.u_cap) atomicMax(reach + i, j);
                     m_loc = best < m_loc ? best : m_loc;
+                }
+            } else if constexpr (CAPPED) {
+                bool done = false;
+                if constexpr (RTK >= 0)
+                    if (R <= RTK && staged) {
+                        m_loc = st_relax_layer_capped<StCell<RTK>>(a, sh, rg, sh.down, sh.up, i, N, R, d_lim, m_prev, reach);
+                        done = true;
+                    }
+                if (!done) {
+                    if (staged) m_loc = st_relax_layer_capped<StCellLds>(a, sh, rg, sh.down, sh.up, i, N, R, d_lim, m_prev, reach);
+                    else m_loc = st_relax_layer_capped<StCellLds>(a, sh, rg, g_down, g_up, i, N, R, d_lim, m_prev, reach);
                 }
             } else if (RTK >= 0) {
                 if constexpr (RTK >= 0) {
-                    if (CAPPED && R <= RTK && staged)
-                        m_loc = st_relax_layer_capped<RTK>(a, sh, rg, i, N, R, d_lim, m_prev);
-                    else if (R <= RTK && RTK <= a.r_tab && staged)
+                    if (R <= RTK && RTK <= a.r_tab && staged)
                         m_loc = st_relax_layer_split<RTK, SPLITK>(a, sh, tb, rg, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
                     else if (staged)
                         m_loc = st_relax_layer<StCellLds>(a, sh, rg, sh.down, sh.up, i, n_s, N, R, d_lim, m_prev, cost_g, pre_g);
@@ -787,21 +849,29 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     };
 
     const StRange whole{n_s, 0, n_s - 1, MP_INF, nullptr, nullptr};
-    const int kA = a.k_prefix + 1; // cells of the first sweep
-    bool two_sweeps = false;
-    if constexpr (RTK >= 0 && !TABLES) two_sweeps = a.k_prefix > 0 && n_s > kA;
-    if constexpr (RTK >= 0 && !TABLES) if (two_sweeps) {
+    if constexpr (!TABLES) if (two_sweeps) {
         // (kept rows: behind the cell records; see st_keep_offset)
-        double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.k_prefix) / 8;
+        double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.rec_cells) / 8;
         double *m_keep = keep_c + (size_t)n_t * kA;
         int *keep_h = (int *)(m_keep + n_t);
+        int *reach = keep_h + (size_t)n_t * kA;
         const StRange first{n_s, 0, kA - 1, MP_INF, nullptr, nullptr};
-        const double u = sweep(first, std::false_type(), false, keep_c, keep_h, kA, m_keep);
+        const double u = sweep(first, std::false_type(), false, keep_c, keep_h, kA, m_keep, nullptr);
+        // per layer, the last of the first sweep's cells within the bound (the second sweep's cells join in)
+        for (int i = 1 + wave; i < n_t; i += nw) {
+            int jm = -1;
+            for (int j0 = 0; j0 < kA; j0 += MP_WAVE) {
+                const int j = j0 + (tid & (MP_WAVE - 1));
+                const unsigned long long m = __ballot(j < kA && keep_c[(size_t)i * kA + j] <= u);
+                if (m) jm = j0 + 63 - __clzll((long long)m);
+            }
+            if ((tid & (MP_WAVE - 1)) == 0) reach[i] = jm;
+        }
         __syncthreads(); // the first sweep is done with the rows and the minimum buffers
         const StRange rest{n_s, kA, n_s - 1, u, nullptr, nullptr};
-        sweep(rest, std::true_type(), true, keep_c, keep_h, kA, m_keep);
+        sweep(rest, std::true_type(), true, keep_c, keep_h, kA, m_keep, reach);
     }
-    if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, nullptr, 0, nullptr);
+    if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, nullptr, 0, nullptr, nullptr);
     __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
@@ -1194,27 +1264,39 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // the 8 the lanes-per-cell relaxation takes; a layer with more is read from global memory
     const int r_slots_1 = r_max > 0 ? r_max : 1;
     const int r_pitch = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024 ? r_slots_1 : 8;
-    // the instances for large batches plan the cells a vehicle within the speed limit can reach
-    // first (see st_dp_body): cells 0..k, k = (cells per layer at the first speed above the
-    // limit) x (layers)
     int rk = r_max == 7 ? 8 : r_max;
     if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() <= 0) || cost || pre) rk = -1;
+    // large batches (throughput; a single plan would only gain barriers) plan the cells a vehicle
+    // within the speed limit can reach first (see st_dp_body): cells 0..k, k = (cells per layer
+    // at the first speed above the limit) x (layers).  Not when the maps are wanted: those hold
+    // every cell's exact cost.
     int k_prefix = 0;
-    if (rk >= 0 && n_t >= 3) {
+    if (B > 512 && !cost && !pre && mp_knob_st_generic() != 2 && n_t >= 3) {
         int d_over = 0;
         while (d_over < n_s_max && !(1.0 * d_over * ds / dt > speed_lim)) ++d_over;
         int k = d_over * (n_t - 1);
+        // (a first sweep over most of the grid would cost what the whole costs, and the second comes
+        // on top; the kernel decides per scenario as well, by its own grid width)
+        if (2 * (k + 1) > n_s_max) k = 0;
+        // The kernel for every path plans in one sweep unless the knob says otherwise: in the whole
+        // replan's scenes (0.26 intervals per layer on average, grids of 74..100 cells of which the
+        // first sweep would take 41) two sweeps cost 5 % more than one, and the room for the kept
+        // rows costs a workgroup per CU (20 % more).
+        if (rk < 0) k = 0;
         if (mp_knob_st_prefix() >= 0) k = mp_knob_st_prefix(); // tests: 0 = one sweep
         if (k > 0 && k + 8 < n_s_max) k_prefix = k;
     }
-    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, k_prefix, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    // (the instances need the room: six workgroups per CU; the kernel for every path, whose grids
+    // take one sweep or two by their interval counts, keeps a record per cell)
+    const int rec_cells = (k_prefix > 0 && rk >= 0) ? k_prefix + 1 : n_s_max;
+    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, k_prefix, rec_cells, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, k_prefix) + st_keep_bytes(n_t, k_prefix);
+    size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, rec_cells) + st_keep_bytes(n_t, k_prefix);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;

@@ -434,6 +434,15 @@ def test_st_many_random_scenarios_every_relaxation_agrees(knob, n_s_hi, r_max, B
         outs["every path, tables, %d lanes" % lanes] = mb.st_dp(*args, LIM, want_tables=True, n_s_max=n_s_hi)
         knob("MP_ST_GENERIC", -1)
     knob("MP_ST_LANES", -1)
+    # the first sweep's cells: none (one sweep), a few (a loose bound on the plan's cost: most cells
+    # of the second sweep are walked), most of the grid
+    for k in (0, 3, n_s_hi // 3, n_s_hi - 10):
+        knob("MP_ST_PREFIX", k)
+        outs["first sweep over %d cells" % (k + 1)] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
+        knob("MP_ST_GENERIC", 1)
+        outs["every path, first sweep over %d cells" % (k + 1)] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
+        knob("MP_ST_GENERIC", -1)
+    knob("MP_ST_PREFIX", -1)
     knob("MP_ST_GENERIC", 2)
     outs["thread per cell"] = mb.st_dp(*args, LIM, want_tables=False, n_s_max=n_s_hi)
     outs["thread per cell, tables"] = mb.st_dp(*args, LIM, want_tables=True, n_s_max=n_s_hi)

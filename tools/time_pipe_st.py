@@ -3,6 +3,7 @@ interval counts of the benchmark's scenes, and the kernel's time under the launc
 
     python3 tools/time_pipe_st.py [B]
 """
+import os
 import sys
 
 import numpy as np
@@ -33,16 +34,18 @@ def main():
           (n_reg[live].mean(), n_reg[live].max(), (n_reg[live] == 0).mean(), (n_reg[live] > 5).mean(),
            (n_reg[live] > 8).mean()))
     args = (a["st_n_s"], a["st_down"], a["st_up"], a["st_n_reg"], a["robot_vel"], params.speed_lim)
+    n_max = int(os.environ.get("PIPE_ST_NMAX", dims.st_n_s_max))   # a tighter bound on the grid width: less LDS
+    print("n_s_max", n_max)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(label):
         out = None
         for _ in range(3):
-            out = mb.st_dp(*args, want_tables=False, n_s_max=dims.st_n_s_max, out=out, ordered=True)
+            out = mb.st_dp(*args, want_tables=False, n_s_max=n_max, out=out, ordered=True)
         ts = []
         for _ in range(20):
             e0.record()
-            out = mb.st_dp(*args, want_tables=False, n_s_max=dims.st_n_s_max, out=out, ordered=True)
+            out = mb.st_dp(*args, want_tables=False, n_s_max=n_max, out=out, ordered=True)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
@@ -50,6 +53,12 @@ def main():
         return out
 
     ref = timed("library's choice")
+    if os.environ.get("ST_AB_ONLY"):
+        _lib.set_knob("MP_ST_PREFIX", 0)
+        o = timed("one sweep")
+        _lib.set_knob("MP_ST_PREFIX", -1)
+        assert torch.equal(o["path_s_ind"], ref["path_s_ind"]) and torch.equal(o["path_len"], ref["path_len"])
+        return
     for thr in (128, 192, 256):
         for lanes in (4, 8):
             _lib.set_knob("MP_ST_THREADS", thr)
