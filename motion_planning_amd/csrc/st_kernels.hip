@@ -12,6 +12,7 @@
 // an integer difference (speed on j-p, acceleration on j-2p+pp, jerk on
 // j-3p+3pp-ppp) are tabulated once per scenario in LDS, which removes all
 // divisions from the edge loop without changing a single bit.
+#include <algorithm>
 #include <type_traits>
 
 #include "mp_device.h"
@@ -45,6 +46,8 @@ struct StDev {
     int32_t r_pitch;                    // interval slots per time layer in LDS (layers with more are read from global memory)
     int32_t k_prefix;                   // > 0: cells 0..k_prefix are planned first, for a bound on the plan's cost (see st_dp_body)
     int32_t rec_cells;                  // cells the LDS cell records are laid out for (n_s_max, or k_prefix + 1)
+    int32_t n_one;                      // with a first sweep: the widest grid that is planned in one sweep all the same
+    int32_t tab_half;                   // the acceleration / jerk tables hold differences -tab_half..tab_half (jerk of layers >= 3: twice that)
     const int32_t *n_s;
     const double *s_down, *s_up;
     const int32_t *n_reg;
@@ -183,9 +186,29 @@ static inline int st_lanes_per_cell(int B, int n_s_max)
     return (B > 512 && n_s_max <= 128) ? 4 : 8;
 }
 
+// Acceleration and jerk terms of an edge as functions of an integer difference of cell indices
+// (speed_planner.py:124-136), with the reference's operations: what the LDS tables hold.
+__device__ __forceinline__ double st_acc_term(const StDev &a, int n, double *acv_out)
+{
+    const double acv = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)n), a.ds), a.dt2);
+    *acv_out = acv;
+    return __dmul_rn(__dmul_rn(acv, acv), a.dt);
+}
+__device__ __forceinline__ double st_jerk2_term(const StDev &a, double acv)
+{
+    const double jk = __ddiv_rn(acv, a.dt);
+    return __dmul_rn(__dmul_rn(jk, jk), a.dt);
+}
+__device__ __forceinline__ double st_jerk3_term(const StDev &a, int m)
+{
+    const double jk = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)m), a.ds), a.dt3);
+    return __dmul_rn(__dmul_rn(jk, jk), a.dt);
+}
+
 struct StSh {
     double *ch_prev, *ch_cur, *fs, *acc, *jerk2, *jerk3, *down, *up;
     short *pre16;
+    int half; // acc / jerk2: index n + half; jerk3: index m + 2 * half
     __device__ __forceinline__ double &cost_prev(int p) const { return ch_prev[2 * p]; }
     __device__ __forceinline__ double &cost_cur(int j) const { return ch_cur[2 * j]; }
     __device__ __forceinline__ double &front(int d) const { return fs[2 * d]; }
@@ -208,9 +231,6 @@ __device__ __forceinline__ int st_store_hist(const StSh &sh, int i, int N, int j
 // cost cannot exceed (MP_INF: none known); a candidate whose cost is certain to exceed it need
 // not be priced (see st_dp_body).  keep_cost / keep_hist (may be null): where the cells' costs
 // and history words of this layer are kept beside the cost row, indexed by cell.
-#ifndef ST_TWO_SWEEP_REGS
-#define ST_TWO_SWEEP_REGS 2 // intervals per layer, on average, from which a grid is planned in two sweeps
-#endif
 struct StRange {
     int n_s; // cells of the scenario's grid
     int j_lo, j_hi;
@@ -258,12 +278,12 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
             const int pp = pre1[p];
             const int n = d - (p - pp);
             double jc;
-            if (i == 2) jc = sh.jerk2[n + (n_s - 1)];
+            if (i == 2) jc = sh.jerk2[n + sh.half];
             else {
                 const int ppp = pre2[pp];
-                jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * (n_s - 1)];
+                jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * sh.half];
             }
-            const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + (n_s - 1)]), jc);
+            const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + sh.half]), jc);
             const double c = __dadd_rn(tot, cp);
             if (bp < 0 || c <= best) { best = c; bp = p; } // lower index wins ties
         }
@@ -298,7 +318,6 @@ __device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const St
                                                         int d_lim, double m_prev, int *reach)
 {
     const double ds = a.ds, u_cap = rg.u_cap;
-    const int n_s1 = rg.n_s - 1;
     const short *pre1 = sh.pre16 + (size_t)(i - 1) * N;
     const short *pre2 = sh.pre16 + (size_t)(i >= 2 ? i - 2 : 0) * N;
     const int j_reach = reach[i - 1] >= 0 ? reach[i - 1] : N;
@@ -324,13 +343,21 @@ __device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const St
                 ST_CNT_LANE(1);
                 const int pp = pre1[p];
                 const int n = d - (p - pp);
-                double jc;
-                if (i == 2) jc = sh.jerk2[n + n_s1];
-                else {
-                    const int ppp = pre2[pp];
-                    jc = sh.jerk3[(j - 3 * p + 3 * pp - ppp) + 2 * n_s1];
+                // (the tables of a launch with a first sweep end where its cells' differences end;
+                // the few edges priced here compute what lies beyond)
+                double jc, ac, acv;
+                const bool n_in = abs(n) <= sh.half;
+                if (n_in) ac = sh.acc[n + sh.half];
+                else ac = st_acc_term(a, n, &acv);
+                if (i == 2) {
+                    if (n_in) jc = sh.jerk2[n + sh.half];
+                    else jc = st_jerk2_term(a, acv);
+                } else {
+                    const int m = j - 3 * p + 3 * pp - pre2[pp];
+                    if (abs(m) <= 2 * sh.half) jc = sh.jerk3[m + 2 * sh.half];
+                    else jc = st_jerk3_term(a, m);
                 }
-                const double tot = __dadd_rn(__dadd_rn(base, sh.acc[n + n_s1]), jc);
+                const double tot = __dadd_rn(__dadd_rn(base, ac), jc);
                 const double c = __dadd_rn(tot, cp);
                 if (c <= best) { best = c; bp = p; } // lower index wins ties
             }
@@ -359,9 +386,9 @@ struct StTab {
 __host__ __device__ __forceinline__ int st_rec_stride(int r_tab) { return r_tab > 0 ? 2 * r_tab + 4 : 1; }
 
 // Bytes of dynamic LDS in front of the cell records (see st_dp_kernel).
-__host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t)
+__host__ __device__ __forceinline__ size_t st_tab_offset(int N, int r_max, int n_t, int tab_half)
 {
-    size_t b = ((size_t)14 * N + 2 * r_max + n_t + 16) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
+    size_t b = ((size_t)6 * N + 8 * (tab_half + 1) + 2 * r_max + n_t + 16) * sizeof(double) + ((size_t)n_t * N + 1) * sizeof(short) +
                2 * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -376,9 +403,10 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 // Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
 // layers' minima over them (double [n_t]), their history words (int [n_t][k+1]) and, per layer, the
 // last cell that costs no more than the bound (int [n_t]).
-__host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int rec_cells)
+__host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int rec_cells,
+                                                          int tab_half)
 {
-    const size_t b = st_tab_offset(N, r_slots, n_t) + st_tab_bytes(rec_cells, r_tab);
+    const size_t b = st_tab_offset(N, r_slots, n_t, tab_half) + st_tab_bytes(rec_cells, r_tab);
     return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ __forceinline__ size_t st_keep_bytes(int n_t, int k_prefix)
@@ -417,7 +445,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const double ds = a.ds;
-    const int n1 = n_s - 1;
+    const int n1 = sh.half;
     // (every record's quiet word and flag word are at their reset values: set at the start of the
     // plan and put back by whoever read them last, see below)
     const double front_step = sh.front(n_s > 1 ? 1 : 0);
@@ -571,7 +599,7 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
 }
 
 // One workgroup per scenario, one thread per s cell.  Dynamic LDS (N = n_s_max):
-//   fs[N][2] row0[N][2] row1[N][2] acc[2N] jerk2[2N] jerk3[4N]
+//   fs[N][2] row0[N][2] row1[N][2] acc[2W+2] jerk2[2W+2] jerk3[4W+4]   (W = tab_half)
 //   down[n_t][r_pitch] up[n_t][r_pitch] last_col[n_t] red[2][8] | pre16[n_t][N] i16 | d_lim
 //   | cell records [N][2 r_tab + 4] (see StTab)
 // TABLES: the cost / predecessor tables are written to global memory.
@@ -597,15 +625,17 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     sh.fs = smem;
     sh.ch_prev = sh.fs + 2 * N;
     sh.ch_cur = sh.ch_prev + 2 * N;
-    sh.acc = sh.ch_cur + 2 * N;    // index n + (n_s-1), n in [-(n_s-1), n_s-1]
-    sh.jerk2 = sh.acc + 2 * N;     // same index, layer i == 2
-    sh.jerk3 = sh.jerk2 + 2 * N;   // index m + 2(n_s-1), layers i >= 3
+    const int W = a.tab_half;
+    sh.half = W;
+    sh.acc = sh.ch_cur + 2 * N;        // index n + W, n in [-W, W]
+    sh.jerk2 = sh.acc + 2 * (W + 1);   // same index, layer i == 2
+    sh.jerk3 = sh.jerk2 + 2 * (W + 1); // index m + 2W, layers i >= 3
     // blocked intervals of every time layer, r_pitch slots each, staged once at the start; a layer
     // with more intervals than that (it takes the thread-per-cell relaxation anyway) reads them
     // from global memory
     const int pitch = a.r_pitch;
     const int R_slots = pitch * n_t;
-    double *down_all = sh.jerk3 + 4 * N, *up_all = down_all + R_slots;
+    double *down_all = sh.jerk3 + 4 * (W + 1), *up_all = down_all + R_slots;
     sh.down = down_all;
     sh.up = up_all;
     double *last_col = up_all + R_slots;
@@ -613,7 +643,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     sh.pre16 = (short *)(red + 16);
     int *d_lim_sh = (int *)(sh.pre16 + (size_t)n_t * N + (((size_t)n_t * N) & 1));
     StTab tb; // placed by offset from smem so the pointers stay LDS pointers
-    tb.rec = smem + st_tab_offset(N, R_slots, n_t) / 8;
+    tb.rec = smem + st_tab_offset(N, R_slots, n_t, W) / 8;
     tb.r_tab = a.r_tab;
     tb.stride = st_rec_stride(a.r_tab);
 
@@ -641,17 +671,16 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         }
         sh.speed(d) = sc;
     }
-    for (int q = tid; q < 2 * n_s - 1; q += nt) {
-        int n = q - (n_s - 1);
-        double acv = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)n), ds), dt2);
-        sh.acc[q] = __dmul_rn(__dmul_rn(acv, acv), dt);
-        double jk = __ddiv_rn(acv, dt);
-        sh.jerk2[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
+    const int h_tab = min(n_s - 1, W); // differences this grid can ask the tables for
+    for (int q = tid; q < 2 * h_tab + 1; q += nt) {
+        const int n = q - h_tab;
+        double acv;
+        sh.acc[n + W] = st_acc_term(a, n, &acv);
+        sh.jerk2[n + W] = st_jerk2_term(a, acv);
     }
-    for (int q = tid; q < 4 * n_s - 3; q += nt) {
-        int m = q - 2 * (n_s - 1);
-        double jk = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)m), ds), dt3);
-        sh.jerk3[q] = __dmul_rn(__dmul_rn(jk, jk), dt);
+    for (int q = tid; q < 4 * h_tab + 1; q += nt) {
+        const int m = q - 2 * h_tab;
+        sh.jerk3[m + 2 * W] = st_jerk3_term(a, m);
     }
     // row 0: cost 0, pre_ind -1 (st_map.py:86-91)
     for (int j = tid; j < N; j += nt) {
@@ -662,26 +691,13 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     }
     if (tid == 0) last_col[0] = 0.0;
     // Two sweeps (see below) pay when the first covers less than half of the grid; a narrower grid
-    // is planned in one, its cell records running on into the room of the first sweep's kept rows
-    // where that is needed (and as far as that room goes).
+    // is planned in one (n_one: up to twice the first sweep's cells, as far as the records, running
+    // on into the room of the kept rows, and the tables go).
     const int kA = a.k_prefix + 1; // cells of the first sweep
     bool two_sweeps = false;
     if constexpr (!TABLES)
         if (a.k_prefix > 0) {
-            const int room = a.rec_cells >= N ? N
-                           : (int)((st_tab_bytes(a.rec_cells, a.r_tab) + st_keep_bytes(n_t, a.k_prefix)) /
-                                   (st_rec_stride(a.r_tab) * sizeof(double)));
-            two_sweeps = n_s > min(2 * kA - 1, room);
-            // ... and when the cells beyond the first sweep are dear ones: a cell inside an interval
-            // or up to 25 m past one carries a constant far above any plan's cost, which no walk of
-            // the one sweep can prune against (its own best holds that constant too); a grid with few
-            // intervals has few such cells.  (A grid wider than the records have room for takes two
-            // sweeps in any case.)
-            if (two_sweeps && n_s <= room) {
-                int regs = 0;
-                for (int i = 1; i < n_t; ++i) regs += a.n_reg[(size_t)b * n_t + i];
-                two_sweeps = regs >= ST_TWO_SWEEP_REGS * (n_t - 1);
-            }
+            two_sweeps = n_s > a.n_one;
         }
     // quiet and flag word of every cell record at their reset values (whoever reads them puts them back)
     for (int j = tid; j < (two_sweeps ? kA : n_s); j += nt) {
@@ -851,7 +867,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     const StRange whole{n_s, 0, n_s - 1, MP_INF, nullptr, nullptr};
     if constexpr (!TABLES) if (two_sweeps) {
         // (kept rows: behind the cell records; see st_keep_offset)
-        double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.rec_cells) / 8;
+        double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.rec_cells, W) / 8;
         double *m_keep = keep_c + (size_t)n_t * kA;
         int *keep_h = (int *)(m_keep + n_t);
         int *reach = keep_h + (size_t)n_t * kA;
@@ -1266,15 +1282,17 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     const int r_pitch = (size_t)2 * r_slots_1 * n_t * sizeof(double) <= 6 * 1024 ? r_slots_1 : 8;
     int rk = r_max == 7 ? 8 : r_max;
     if (!(B >= 2048 && rk <= 8 && rk <= r_tab && mp_knob_st_generic() <= 0) || cost || pre) rk = -1;
-    // large batches (throughput; a single plan would only gain barriers) plan the cells a vehicle
-    // within the speed limit can reach first (see st_dp_body): cells 0..k, k = (cells per layer
-    // at the first speed above the limit) x (layers).  Not when the maps are wanted: those hold
-    // every cell's exact cost.
+    // Large batches (throughput; a single plan would only gain barriers) plan the nearest cells
+    // first (see st_dp_body): cells 0..k, k = half of what a vehicle reaches that never exceeds
+    // the speed limit ((cells per layer at the first speed above the limit) x (layers) / 2).  Any
+    // k gives the same plans; a small one makes the first sweep cheap and its bound loose (on the
+    // benchmark's 97-cell grids, 4096 plans: k = 40 / 30 / 20 / 10 -> 0.226 / 0.218 / 0.207 /
+    // 0.220 ms).  Not when the maps are wanted: those hold every cell's exact cost.
     int k_prefix = 0;
     if (B > 512 && !cost && !pre && mp_knob_st_generic() != 2 && n_t >= 3) {
         int d_over = 0;
         while (d_over < n_s_max && !(1.0 * d_over * ds / dt > speed_lim)) ++d_over;
-        int k = d_over * (n_t - 1);
+        int k = d_over * (n_t - 1) / 2;
         // (a first sweep over most of the grid would cost what the whole costs, and the second comes
         // on top; the kernel decides per scenario as well, by its own grid width)
         if (2 * (k + 1) > n_s_max) k = 0;
@@ -1289,14 +1307,26 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // (the instances need the room: six workgroups per CU; the kernel for every path, whose grids
     // take one sweep or two by their interval counts, keeps a record per cell)
     const int rec_cells = (k_prefix > 0 && rk >= 0) ? k_prefix + 1 : n_s_max;
-    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, k_prefix, rec_cells, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
+    // the widest grid that is still planned in one sweep, and with it how far the tables must go
+    // (the second sweep computes what it needs beyond them)
+    int n_one = n_s_max, tab_half = n_s_max - 1;
+    if (k_prefix > 0) {
+        const int room = rec_cells >= n_s_max ? n_s_max
+                       : (int)((st_tab_bytes(rec_cells, r_tab) + st_keep_bytes(n_t, k_prefix)) /
+                               (st_rec_stride(r_tab) * sizeof(double)));
+        n_one = std::min(2 * (k_prefix + 1) - 1, room);
+        if (rec_cells < n_s_max) tab_half = std::max(n_one - 1, k_prefix);
+    }
+    StDev a{n_t, n_s_max, r_slots_1, r_tab, st_lanes_per_cell(B, n_s_max), r_pitch, k_prefix, rec_cells, n_one, tab_half, n_s, s_down, s_up, n_reg, cur_vel, speed_lim, ds, dt,
             pow(dt, 2.0), pow(dt, 3.0), cost, pre, path_s_ind, path_len, nullptr};
     int threads = n_s_max <= 32 ? 64 : (n_s_max <= 64 ? 128 : 256);
     // few scenarios (less than two workgroups per CU): latency counts, not throughput, so a
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
+    // with a first sweep a layer's pass is over its cells only (and most of the others are never walked)
+    if (k_prefix > 0 && rk >= 0 && (k_prefix + 1) * a.lanes_per_cell <= 128) threads = std::min(threads, 128);
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
-    size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, rec_cells) + st_keep_bytes(n_t, k_prefix);
+    size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, rec_cells, tab_half) + st_keep_bytes(n_t, k_prefix);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
     const dim3 grid(B), block(threads);
     hipStream_t st = (hipStream_t)stream;
