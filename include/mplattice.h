@@ -33,9 +33,10 @@
  * MP_ST_THREADS=n / MP_RL_THREADS=n / MP_FE_THREADS=n / MP_CV_THREADS=n (workgroup
  * size of mp_st_dp / mp_refline_tables / the front end / the two spline stages of
  * mp_plan_scenes; honoured only when a multiple of 64 within 64..1024), MP_ST_LANES=4|8 (lanes that share a
- * cell in mp_st_dp's relaxation), MP_ST_PREFIX=k (mp_st_dp's instances for large
- * batches plan cells 0..k first and bound the rest of the grid by their result;
- * 0: one sweep over the whole grid), MP_SL_ROWS=n (predecessor rows mp_sl_plan's
+ * cell in mp_st_dp's relaxation), MP_ST_PREFIX=k (large batches of mp_st_dp plan
+ * cells 0..k first and bound the rest of the grid by their result, on the kernel
+ * for every path too, which plans in one sweep by default; 0: one sweep over the
+ * whole grid), MP_SL_ROWS=n (predecessor rows mp_sl_plan's
  * kernel keeps in LDS before it leaves a scenario to its second launch).
  */
 #ifndef MPLATTICE_H
