@@ -229,14 +229,13 @@ __device__ __forceinline__ int st_store_hist(const StSh &sh, int i, int N, int j
 
 // The cells a relaxation call takes: j_lo..j_hi of the layer.  u_cap: a number the plan's final
 // cost cannot exceed (MP_INF: none known); a candidate whose cost is certain to exceed it need
-// not be priced (see st_dp_body).  keep_cost / keep_hist (may be null): where the cells' costs
-// and history words of this layer are kept beside the cost row, indexed by cell.
+// not be priced (see st_dp_body).  keep_cost (may be null): where the cells' costs of this layer
+// are kept beside the cost row, indexed by cell.
 struct StRange {
     int n_s; // cells of the scenario's grid
     int j_lo, j_hi;
     double u_cap;
     double *keep_cost;
-    int *keep_hist;
 };
 
 // All cells of time layer i >= 2 owned by this thread.
@@ -289,11 +288,8 @@ __device__ __forceinline__ double st_relax_layer(const StDev &a, const StSh &sh,
         }
         sh.cost_cur(j) = best;
         sh.pre16[(size_t)i * N + j] = (short)bp;
-        const int hist = st_store_hist(sh, i, N, j, bp);
-        if (rg.keep_cost) {
-            rg.keep_cost[j] = best;
-            rg.keep_hist[j] = hist;
-        }
+        st_store_hist(sh, i, N, j, bp);
+        if (rg.keep_cost) rg.keep_cost[j] = best;
         if (cost_g) cost_g[(size_t)i * N + j] = best;
         if (pre_g) pre_g[(size_t)i * N + j] = bp;
         m_loc = best < m_loc ? best : m_loc;
@@ -401,8 +397,8 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 // intervals in registers, and a scenario of such a launch that is planned in one sweep has the
 // kept rows' room behind the records for its other cells; see st_dp_body.)
 // Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
-// layers' minima over them (double [n_t]), their history words (int [n_t][k+1]) and, per layer, the
-// last cell that costs no more than the bound (int [n_t]).
+// layers' minima over them (double [n_t]) and, per layer, the last cell that costs no more than the
+// bound (int [n_t]).  (Their history words are written again from the predecessor rows.)
 __host__ __device__ __forceinline__ size_t st_keep_offset(int N, int r_slots, int n_t, int r_tab, int rec_cells,
                                                           int tab_half)
 {
@@ -413,7 +409,7 @@ __host__ __device__ __forceinline__ size_t st_keep_bytes(int n_t, int k_prefix)
 {
     if (k_prefix <= 0) return 0;
     const size_t cells = (size_t)n_t * (k_prefix + 1);
-    return (cells + n_t) * sizeof(double) + (cells + n_t) * sizeof(int);
+    return (cells + n_t) * sizeof(double) + n_t * sizeof(int);
 }
 
 // All cells of time layer i >= 2, ST_SPLIT lanes per cell.
@@ -585,11 +581,8 @@ __device__ __forceinline__ double st_relax_layer_split(const StDev &a, const StS
         if (live && r == 0) {
             sh.cost_cur(j) = best;
             sh.pre16[(size_t)i * N + j] = (short)bp;
-            const int hist = st_store_hist(sh, i, N, j, bp);
-            if (rg.keep_cost) {
-                rg.keep_cost[j] = best;
-                rg.keep_hist[j] = hist;
-            }
+            st_store_hist(sh, i, N, j, bp);
+            if (rg.keep_cost) rg.keep_cost[j] = best;
             if (cost_g) cost_g[(size_t)i * N + j] = best;
             if (pre_g) pre_g[(size_t)i * N + j] = bp;
             m_loc = best < m_loc ? best : m_loc;
@@ -717,7 +710,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
 
     // One sweep over the time layers for the cells rg.j_lo..rg.j_hi.  Cell j only looks at cells
     // 0..j of the layer before, so the cells 0..k can be planned through all layers on their own
-    // (first sweep: their costs and history words of every layer are kept), and the cheapest of
+    // (first sweep: their costs of every layer are kept), and the cheapest of
     // them in the last layer bounds the plan's final cost from above: the end state is the
     // cheaper of the cheapest cell of the last layer and the cheapest last cell of any layer, so
     // it costs at most u.  Costs never decrease along a chain of predecessors (every term of an
@@ -728,7 +721,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     // cost at most u come out exactly as without the bound (costs and predecessors), cells
     // above it with some value above it, and the end state and its chain are the same.  Most of a
     // grid is such cells (far ahead, behind obstacles), and their walks were the long ones.
-    auto sweep = [&](const StRange &rg0, auto capped_tag, bool second, double *keep_c, int *keep_h, int kA,
+    auto sweep = [&](const StRange &rg0, auto capped_tag, bool second, double *keep_c, int kA,
                      double *m_keep, int *reach) -> double {
         constexpr bool CAPPED = decltype(capped_tag)::value;
         double m_prev = 0.0; // minimum of cost_prev
@@ -744,7 +737,6 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             StRange rg = rg0;
             if (keep_c && !second) { // first sweep: this layer's row of the kept costs
                 rg.keep_cost = keep_c + (size_t)i * kA;
-                rg.keep_hist = keep_h + (size_t)i * kA;
             }
             double m_loc = MP_INF;
             if (i == 1) {
@@ -767,11 +759,8 @@ __device__ __forceinline__ void st_dp_body(StDev a)
                                             __dmul_rn(__dmul_rn(jk, jk), dt));
                     sh.cost_cur(j) = best;
                     sh.pre16[(size_t)i * N + j] = 0;
-                    const int hist = st_store_hist(sh, i, N, j, 0);
-                    if (rg.keep_cost) {
-                        rg.keep_cost[j] = best;
-                        rg.keep_hist[j] = hist;
-                    }
+                    st_store_hist(sh, i, N, j, 0);
+                    if (rg.keep_cost) rg.keep_cost[j] = best;
                     if (cost_g) cost_g[(size_t)i * N + j] = best;
                     if (pre_g) pre_g[(size_t)i * N + j] = 0;
                     if constexpr (CAPPED)
@@ -839,7 +828,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             if (second)
                 for (int j = tid; j < kA; j += nt) {
                     sh.cost_cur(j) = keep_c[(size_t)i * kA + j];
-                    *(int *)(sh.ch_cur + 2 * j + 1) = keep_h[(size_t)i * kA + j];
+                    st_store_hist(sh, i, N, j, sh.pre16[(size_t)i * N + j]); // (the word it had in the first sweep)
                 }
             // (a layer that takes the thread-per-cell relaxation has no barrier of its own: a wave
             // may be writing the next layer's minimum while another still reads this one's, hence
@@ -864,15 +853,14 @@ __device__ __forceinline__ void st_dp_body(StDev a)
         return m_prev;
     };
 
-    const StRange whole{n_s, 0, n_s - 1, MP_INF, nullptr, nullptr};
+    const StRange whole{n_s, 0, n_s - 1, MP_INF, nullptr};
     if constexpr (!TABLES) if (two_sweeps) {
         // (kept rows: behind the cell records; see st_keep_offset)
         double *keep_c = smem + st_keep_offset(N, R_slots, n_t, a.r_tab, a.rec_cells, W) / 8;
         double *m_keep = keep_c + (size_t)n_t * kA;
-        int *keep_h = (int *)(m_keep + n_t);
-        int *reach = keep_h + (size_t)n_t * kA;
-        const StRange first{n_s, 0, kA - 1, MP_INF, nullptr, nullptr};
-        const double u = sweep(first, std::false_type(), false, keep_c, keep_h, kA, m_keep, nullptr);
+        int *reach = (int *)(m_keep + n_t);
+        const StRange first{n_s, 0, kA - 1, MP_INF, nullptr};
+        const double u = sweep(first, std::false_type(), false, keep_c, kA, m_keep, nullptr);
         // per layer, the last of the first sweep's cells within the bound (the second sweep's cells join in)
         for (int i = 1 + wave; i < n_t; i += nw) {
             int jm = -1;
@@ -884,10 +872,10 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             if ((tid & (MP_WAVE - 1)) == 0) reach[i] = jm;
         }
         __syncthreads(); // the first sweep is done with the rows and the minimum buffers
-        const StRange rest{n_s, kA, n_s - 1, u, nullptr, nullptr};
-        sweep(rest, std::true_type(), true, keep_c, keep_h, kA, m_keep, reach);
+        const StRange rest{n_s, kA, n_s - 1, u, nullptr};
+        sweep(rest, std::true_type(), true, keep_c, kA, m_keep, reach);
     }
-    if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, nullptr, 0, nullptr, nullptr);
+    if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, 0, nullptr, nullptr);
     __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
     if (tid == 0) {
@@ -1293,6 +1281,10 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         int d_over = 0;
         while (d_over < n_s_max && !(1.0 * d_over * ds / dt > speed_lim)) ++d_over;
         int k = d_over * (n_t - 1) / 2;
+        // ... rounded down to whole waves of the first sweep (its lanes are the issue slots a pass
+        // costs, filled or not: 16 cells instead of 21 on the benchmark, 0.174 -> 0.162 ms)
+        const int per_wave = MP_WAVE / st_lanes_per_cell(B, n_s_max);
+        if (k + 1 > per_wave) k = (k + 1) / per_wave * per_wave - 1;
         // (a first sweep over most of the grid would cost what the whole costs, and the second comes
         // on top; the kernel decides per scenario as well, by its own grid width)
         if (2 * (k + 1) > n_s_max) k = 0;
