@@ -2039,8 +2039,10 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
 #undef SLN_LAUNCH
         return launch_check("mp_sl_plan");
     }
-    // pair store: 3.5 pairs per obstacle slot (an obstacle of radius r meets about
-    // 2r/d_s + 1 samples, a few of them twice where two layers share a sample),
+    // pair store: 5 pairs per obstacle slot (an obstacle of radius r meets about
+    // 2r/d_s + 1 samples, a few of them twice where two layers share a sample; the benchmark's
+    // scenarios have 146 pairs on average and 227 at most for 50 obstacles, and laying the
+    // store out again for the quarter of them that 175 entries did not hold cost 5 %),
     // fewer if LDS would not hold it; layers past its end test their pairs directly
     const int threads = ((n_l + 63) / 64) * 64;
     const bool shared_row = batch->l_rstride == 0;
@@ -2055,12 +2057,13 @@ static int sl_plan_launch(const mp_sl_batch *batch, const mp_sl_params *params, 
     const int rows_compact = mp_knob_sl_rows() > 0 ? mp_knob_sl_rows() : SL_ROWS_COMPACT; // tests: force the second launch
     const bool compact = shared_row && !maps && !n_evaluated && n_s > rows_compact;
     const int rows = compact ? rows_compact : n_s;
-    int cap = (7 * batch->ob_stride) / 2;
+    int cap = 5 * batch->ob_stride;
     if (mp_knob_sl_pair_cap() >= 0) cap = mp_knob_sl_pair_cap(); // tests: force the overflow path
     else {
         // registers allow 16 waves per CU; a store that lets LDS hold fewer workgroups than
         // that costs more (idle SIMDs) than laying a smaller store out again every few layers
-        const size_t budget = (size_t)10 * 1024 * (threads / 64), fixed = sl_plan_lds_bytes(n_s, n_l, 0, rows);
+        // (512 B less than the CU's share: the kernel's static LDS and the allocation granule)
+        const size_t budget = (size_t)10 * 1024 * (threads / 64) - 512, fixed = sl_plan_lds_bytes(n_s, n_l, 0, rows);
         const int fit = budget > fixed ? (int)((budget - fixed) / (3 * sizeof(double) + 2)) : 0;
         const int floor_cap = 128;
         if (cap > fit) cap = fit > floor_cap ? fit : (cap < floor_cap ? cap : floor_cap);
