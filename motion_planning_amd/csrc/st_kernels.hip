@@ -22,7 +22,8 @@
 // split relaxation do.  0 wave steps, 1 lane steps (edges priced), 2 wave steps that took
 // the quiet obstacle sum, 4 lanes stopped by the bound, 5 wave passes, 8 first wave steps,
 // 9 / 10 later lane steps that did / did not improve the lane's best; 11 / 12 cells of a second
-// sweep that were not priced / all of them (their priced edges count as lane steps too).
+// sweep that were not priced / all of them (their priced edges count as lane steps too), 13 those
+// of them that were too far ahead for their intervals to be looked at.
 __device__ unsigned long long st_cnt[16];
 #define ST_CNT_WAVE(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) atomicAdd(&st_cnt[i], 1ull); } while (0)
 #define ST_CNT_LANE(i) atomicAdd(&st_cnt[i], 1ull)
@@ -319,13 +320,26 @@ __device__ __forceinline__ double st_relax_layer_capped(const StDev &a, const St
     const int j_reach = reach[i - 1] >= 0 ? reach[i - 1] : N;
     double m_loc = MP_INF;
     for (int j = rg.j_lo + threadIdx.x; j <= rg.j_hi; j += blockDim.x) {
+        double best = MP_INF;
+        int bp = j;
+        ST_CNT_LANE(12);
+        // Too far ahead of every cell within the bound: the slowest edge that reaches the cell from
+        // one of them is above the speed limit (from there on the speed term only grows with the
+        // distance), and that term alone, on the cheapest cell of the layer before, exceeds the
+        // bound; every candidate would be stopped or skipped by the tests below, so the cell's
+        // intervals are not even looked at.  (Whole waves of cells at the far end of the grid.)
+        const int d0 = j - min(j, j_reach);
+        if (d0 >= d_lim && __dadd_rn(sh.speed(d0), m_prev) > u_cap) {
+            ST_CNT_LANE(13);
+            sh.cost_cur(j) = best;
+            sh.pre16[(size_t)i * N + j] = (short)bp;
+            st_store_hist(sh, i, N, j, bp);
+            continue;
+        }
         const double s = __dmul_rn((double)j, ds);
         CELL cell;
         cell.init(s, down, up, R);
         const double ob_quiet = cell.quiet(s);
-        double best = MP_INF;
-        int bp = j;
-        ST_CNT_LANE(12);
         if (cell.monotone && __dadd_rn(ob_quiet, m_prev) > u_cap) {
             ST_CNT_LANE(11);
         } else {
@@ -742,6 +756,14 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             if (i == 1) {
                 // only p_j = 0 (speed_planner.py:96-100)
                 for (int j = rg.j_lo + tid; j <= rg.j_hi; j += nt) {
+                    if constexpr (CAPPED)
+                        if (j >= d_lim && sh.speed(j) > rg.u_cap) {
+                            // (the speed term of the one edge into the cell is above the bound already)
+                            sh.cost_cur(j) = MP_INF;
+                            sh.pre16[(size_t)i * N + j] = 0;
+                            st_store_hist(sh, i, N, j, 0);
+                            continue;
+                        }
                     const double s = __dmul_rn((double)j, ds);
                     double v = __ddiv_rn(__dmul_rn(__dmul_rn(1.0, (double)j), ds), dt);
                     double ac = __ddiv_rn(__dsub_rn(v, v0), dt);
@@ -878,15 +900,20 @@ __device__ __forceinline__ void st_dp_body(StDev a)
     if (!two_sweeps) sweep(whole, std::false_type(), false, nullptr, 0, nullptr, nullptr);
     __syncthreads(); // last_col complete
     // end state and backtrack (speed_planner.py:63-89)
-    if (tid == 0) {
+    if (tid < MP_WAVE) {
+        // cheapest cell of the last layer, the first of equals: by one wave
+        double min_j = MP_INF;
+        int arg_j = 0x7fffffff;
+        for (int j = tid; j < n_s; j += MP_WAVE) {
+            const double c = sh.cost_prev(j);
+            if (c < min_j || arg_j == 0x7fffffff) { min_j = c; arg_j = j; }
+        }
+        group_argmin<MP_WAVE>(min_j, arg_j);
+        if (tid == 0) {
         double min_i = last_col[1];
         int arg_i = 1;
         for (int i = 2; i < n_t; ++i)
             if (last_col[i] < min_i) { min_i = last_col[i]; arg_i = i; }
-        double min_j = sh.cost_prev(0);
-        int arg_j = 0;
-        for (int j = 1; j < n_s; ++j)
-            if (sh.cost_prev(j) < min_j) { min_j = sh.cost_prev(j); arg_j = j; }
         int end_i, end_j;
         if (min_i <= min_j) { end_i = arg_i; end_j = n_s - 1; }
         else { end_i = n_t - 1; end_j = arg_j; }
@@ -899,6 +926,7 @@ __device__ __forceinline__ void st_dp_body(StDev a)
             out[i - 1] = j;
         }
         a.path_len[b] = end_i + 1;
+        }
     }
 }
 

@@ -25,6 +25,7 @@ lib.mp_debug_st_counters(out, 0)
 names = {0: "wave steps", 1: "lane steps (edges priced)", 2: "wave steps on the quiet obstacle sum",
          4: "lanes stopped by the bound", 5: "wave passes", 8: "first wave steps",
          9: "later lane steps that improved", 10: "later lane steps that did not",
-         11: "second sweep: cells not priced (constants above the bound)", 12: "second sweep: cells"}
+         11: "second sweep: cells not priced (constants above the bound)", 12: "second sweep: cells",
+         13: "second sweep: cells too far ahead of every cell within the bound"}
 for i, n in names.items():
     print("%-45s %12d  per plan %.1f" % (n, out[i], out[i] / B))
