@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 VALU_FP64_PEAK_TF = 78.6     # MI355X vector fp64 spec (counts a fused multiply-add as two)
 VALU_FP64_NO_FMA_TF = 39.3   # the same pipes when no multiply-add may be fused (bit-exact Python arithmetic)
 ISSUE_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9   # wave64 vector instructions/s: 1024 SIMDs, 4 cycles each, 2.4 GHz
-ST_EDGES_PRICED_PER_PLAN = 977   # of 42 874, on the benchmark's batch (tools/count_st.py, counting build of the speed DP; profiles/r03e_st_counts.txt)
+ST_EDGES_PRICED_PER_PLAN = 977   # of 42 874, on the benchmark's batch (tools/count_st.py, counting build of the speed DP; profiles/r03f_st_counts.txt)
 CFG4_TOTAL = 65536
 
 
