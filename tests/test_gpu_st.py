@@ -319,6 +319,46 @@ def test_st_other_grid_steps(oracle):
         same(out["pre"][b].cpu().numpy(), ref["pre"], "pre[%d]" % b)
 
 
+@pytest.mark.parametrize("lim,ds,dt", [(7.3, 0.7, 0.3), (0.4, 1.0, 0.5), (1e3, 1.0, 0.5), (25.0 * 5.0 / 18.0, 0.5, 0.5),
+                                       (3.0, 2.0, 0.25)])
+def test_st_large_batches_with_other_steps_and_limits(oracle, knob, lim, ds, dt):
+    """A large batch (planned in two sweeps, the first over the cells a vehicle within the speed
+    limit reaches) with other grid steps and speed limits: a limit below the first step (every
+    edge but standing still is above it), one no cell can exceed (no cell is ever too far
+    ahead), half-metre cells.  Against the kernel that writes the tables, the thread-per-cell
+    relaxation and, on a sample, the oracle."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(int(lim * 100) + int(ds * 10))
+    B, n_t, n_s_hi, r_max = 2560, 11, 90, 4
+    n_s = rng.integers(20, n_s_hi + 1, B).astype(np.int32)
+    n_s[:64] = n_s_hi
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    down = rng.uniform(-3.0, n_s_hi * ds + 5.0, (B, n_t, r_max))
+    up = down + rng.uniform(0.0, 6.0, down.shape)
+    cur = rng.uniform(0.0, 2.0 * min(lim, 10.0), B)
+    args = (mb.to_dev(n_s, torch.int32), mb.to_dev(down), mb.to_dev(up), mb.to_dev(n_reg, torch.int32), mb.to_dev(cur))
+    ref = mb.st_dp(*args, lim, ds=ds, dt=dt, want_tables=True, n_s_max=n_s_hi)
+    fast = mb.st_dp(*args, lim, ds=ds, dt=dt, want_tables=False, n_s_max=n_s_hi)
+    knob("MP_ST_PREFIX", 11)
+    fast_k = mb.st_dp(*args, lim, ds=ds, dt=dt, want_tables=False, n_s_max=n_s_hi)
+    knob("MP_ST_GENERIC", 1)
+    gen_k = mb.st_dp(*args, lim, ds=ds, dt=dt, want_tables=False, n_s_max=n_s_hi)
+    knob("MP_ST_PREFIX", -1)
+    knob("MP_ST_GENERIC", 2)
+    cell = mb.st_dp(*args, lim, ds=ds, dt=dt, want_tables=False, n_s_max=n_s_hi)
+    knob("MP_ST_GENERIC", -1)
+    torch.cuda.synchronize()
+    for name, o in (("library's choice", fast), ("first sweep over 12 cells", fast_k),
+                    ("every path, first sweep over 12 cells", gen_k), ("thread per cell", cell)):
+        assert torch.equal(o["path_s_ind"], ref["path_s_ind"]) and torch.equal(o["path_len"], ref["path_len"]), name
+    for b in (0, 1, 64, B - 1):
+        o = oracle.st_find_speed(n_t, int(n_s[b]), down[b], up[b], n_reg[b], float(cur[b]), lim, ds=ds, dt=dt)
+        plen = int(fast["path_len"][b])
+        assert np.array_equal(fast["path_s_ind"][b, :plen].cpu().numpy(), o["path_s_ind"]), b
+        same(ref["cost"][b, :, :n_s[b]].cpu().numpy(), o["cost"], "cost[%d]" % b)
+
+
 def test_st_regions_pipeline_goldens():
     import torch
     from motion_planning_amd import batch as mb
