@@ -1316,17 +1316,15 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         // (a first sweep over most of the grid would cost what the whole costs, and the second comes
         // on top; the kernel decides per scenario as well, by its own grid width)
         if (2 * (k + 1) > n_s_max) k = 0;
-        // The kernel for every path plans in one sweep unless the knob says otherwise: in the whole
-        // replan's scenes (0.26 intervals per layer on average, grids of 74..100 cells of which the
-        // first sweep would take 41) two sweeps cost 5 % more than one, and the room for the kept
-        // rows costs a workgroup per CU (20 % more).
-        if (rk < 0) k = 0;
+        // (the whole replan's scenes, 0.26 intervals per layer on average, grids of 74..100 cells, on
+        // the kernel for every path: ST stage 0.107 ms in one sweep, 0.076 with a first sweep over 16
+        // cells, 0.084 over 32, 0.111 over 48)
         if (mp_knob_st_prefix() >= 0) k = mp_knob_st_prefix(); // tests: 0 = one sweep
         if (k > 0 && k + 8 < n_s_max) k_prefix = k;
     }
     // (the instances need the room: six workgroups per CU; the kernel for every path, whose grids
     // take one sweep or two by their interval counts, keeps a record per cell)
-    const int rec_cells = (k_prefix > 0 && rk >= 0) ? k_prefix + 1 : n_s_max;
+    const int rec_cells = k_prefix > 0 ? k_prefix + 1 : n_s_max;
     // the widest grid that is still planned in one sweep, and with it how far the tables must go
     // (the second sweep computes what it needs beyond them)
     int n_one = n_s_max, tab_half = n_s_max - 1;
@@ -1344,7 +1342,7 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
     // grid gets the lanes that make a layer one pass (8 per cell), up to 512
     if (B <= 512) threads = n_s_max <= 32 ? 256 : 512;
     // with a first sweep a layer's pass is over its cells only (and most of the others are never walked)
-    if (k_prefix > 0 && rk >= 0 && (k_prefix + 1) * a.lanes_per_cell <= 128) threads = std::min(threads, 128);
+    if (k_prefix > 0 && (k_prefix + 1) * a.lanes_per_cell <= 128) threads = std::min(threads, 128);
     if (mp_knob_st_threads() > 0) threads = mp_knob_st_threads(); // development aid
     size_t lds = st_keep_offset(n_s_max, r_pitch * n_t, n_t, r_tab, rec_cells, tab_half) + st_keep_bytes(n_t, k_prefix);
     if (lds > 160 * 1024) { mp_set_error("mp_st_dp: grid too large for LDS"); return MP_E_UNSUPPORTED; }
