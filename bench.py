@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 VALU_FP64_PEAK_TF = 78.6     # MI355X vector fp64 spec (counts a fused multiply-add as two)
 VALU_FP64_NO_FMA_TF = 39.3   # the same pipes when no multiply-add may be fused (bit-exact Python arithmetic)
 ISSUE_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9   # wave64 vector instructions/s: 1024 SIMDs, 4 cycles each, 2.4 GHz
-ST_EDGES_PRICED_PER_PLAN = 977   # of 42 874, on the benchmark's batch (tools/count_st.py, counting build of the speed DP; profiles/r03f_st_counts.txt)
+ST_EDGES_PRICED_PER_PLAN = 977   # of 42 874, on the benchmark's batch (tools/count_st.py, counting build of the speed DP; profiles/r03g_st_counts.txt)
 CFG4_TOTAL = 65536
 
 
@@ -786,11 +786,22 @@ def bench_pipeline(args, job, steps, warmup, reps, cpu_sample):
             r["issue_slots_used"] = k["SQ_INSTS_VALU"] / t / 1e9 / ISSUE_PEAK_GINST
         return r
 
+    # (the speed DP plans the nearest cells first and bounds the rest of the grid by their result, so
+    # most edges are never priced and the reference's flops over its time are not a utilisation: its
+    # entry is priced by its own vector instructions, like the interval kernel's below)
+    st_roof = stage_roof("ST speed DP", "st_dp_kernel", flop_st,
+                         "bound by vector instruction issue: frac = the kernel's own vector instructions "
+                         "(SQ_INSTS_VALU of the committed counter pass) / duration against 1024 SIMDs x 2.4 GHz / 4 "
+                         "cycles.  reference_work_tflops = (30 + 9 R) flop per ST edge over the scenes that reach "
+                         "the speed search, R = that layer's interval count, / duration: what the reference would "
+                         "have had to do, not what the kernel does (two sweeps, exact pruning).  The launch is "
+                         "st_dp_plain_kernel, the build of st_dp_kernel's body for large batches (every relaxation "
+                         "path, no tables, five waves per SIMD)")
+    st_roof.update(bound="valu_issue", unit="G wave-instructions/s", peak=ISSUE_PEAK_GINST,
+                   reference_work_tflops=st_roof["achieved"], frac=st_roof.get("issue_slots_used"),
+                   achieved=st_roof["issue_slots_used"] * ISSUE_PEAK_GINST if st_roof.get("issue_slots_used") else None)
     roofs = [
-        stage_roof("ST speed DP", "st_dp_kernel", flop_st,
-                   "(30 + 9 R) flop per ST edge over the scenes that reach the speed search, R = that layer's "
-                   "interval count; the launch is st_dp_plain_kernel, the build of st_dp_kernel's body for large "
-                   "batches (every relaxation path, no tables, five waves per SIMD)"),
+        st_roof,
         stage_roof("front end (Frenet map, obstacle list)", "plan_frontend_kernel", flop_fe,
                    "(7 M + 40) flop per point to Frenet, M = the scene's reference-line samples; the kernel "
                    "compares only the samples of the blocks whose bounding box can hold the nearest one"),
