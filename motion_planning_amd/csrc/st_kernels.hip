@@ -406,8 +406,8 @@ __host__ __device__ __forceinline__ size_t st_tab_bytes(int N, int r_tab)
 {
     return (size_t)N * st_rec_stride(r_tab) * sizeof(double);
 }
-// (StDev.rec_cells: the cells the records are laid out for: the whole grid, or, in the instances
-// for large batches, the first sweep's cells 0..k_prefix only: the second sweep keeps a cell's
+// (StDev.rec_cells: the cells the records are laid out for: the whole grid, or, in a launch with
+// a first sweep, its cells 0..k_prefix only: the second sweep keeps a cell's
 // intervals in registers, and a scenario of such a launch that is planned in one sweep has the
 // kept rows' room behind the records for its other cells; see st_dp_body.)
 // Behind the records, with a first sweep: its cells' costs of every layer (double [n_t][k+1]), the
@@ -939,7 +939,7 @@ __global__ void st_dp_kernel(StDev a)
 // The kernel that holds every path, without the tables: 101 registers would leave it at four
 // waves per SIMD; at five (96 registers, 12 B of scratch) the whole replan's speed search, whose
 // workgroups mostly wait for LDS round trips and barriers, takes 0.115 instead of 0.134 ms per
-// 4096 scenes (six waves: 56 B of scratch, 0.119).
+// 4096 scenes (six waves: 56 B of scratch, 0.119; measured while it still planned in one sweep).
 __attribute__((amdgpu_waves_per_eu(5, 5))) __global__ void st_dp_plain_kernel(StDev a)
 {
     st_dp_body<false, -1, 0>(a);
@@ -1322,8 +1322,8 @@ static int st_dp_launch(int32_t B, int32_t n_t, int32_t n_s_max, const int32_t *
         if (mp_knob_st_prefix() >= 0) k = mp_knob_st_prefix(); // tests: 0 = one sweep
         if (k > 0 && k + 8 < n_s_max) k_prefix = k;
     }
-    // (the instances need the room: six workgroups per CU; the kernel for every path, whose grids
-    // take one sweep or two by their interval counts, keeps a record per cell)
+    // (records for the first sweep's cells only: with 13 KB of LDS a CU holds the twelve workgroups
+    // the instances' registers allow)
     const int rec_cells = k_prefix > 0 ? k_prefix + 1 : n_s_max;
     // the widest grid that is still planned in one sweep, and with it how far the tables must go
     // (the second sweep computes what it needs beyond them)
