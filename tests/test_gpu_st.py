@@ -359,6 +359,34 @@ def test_st_large_batches_with_other_steps_and_limits(oracle, knob, lim, ds, dt)
         same(ref["cost"][b, :, :n_s[b]].cpu().numpy(), o["cost"], "cost[%d]" % b)
 
 
+@pytest.mark.parametrize("B,n_t,N,r_max", [(2048, 11, 1000, 3), (2048, 40, 300, 2), (600, 11, 1024, 8),
+                                           (2304, 64, 120, 5), (4096, 3, 97, 5)])
+def test_st_extreme_shapes_against_thread_per_cell(knob, B, n_t, N, r_max):
+    """The widest grids, the most and the fewest time layers the library takes, in large batches
+    (two sweeps, records and tables sized by the first one): the instance for the interval bound
+    and the kernel that holds every path against the relaxation by one thread per cell."""
+    import torch
+    from motion_planning_amd import batch as mb
+    rng = np.random.default_rng(B + n_t + N)
+    n_s = rng.integers(N // 2, N + 1, B).astype(np.int32)
+    n_s[0] = N
+    down = rng.uniform(-10.0, N + 20.0, (B, n_t, r_max))
+    up = down + rng.uniform(0.0, 8.0, down.shape)
+    n_reg = rng.integers(0, r_max + 1, (B, n_t)).astype(np.int32)
+    cur = rng.uniform(0.0, 12.0, B)
+    args = (mb.to_dev(n_s, torch.int32), mb.to_dev(down), mb.to_dev(up), mb.to_dev(n_reg, torch.int32), mb.to_dev(cur))
+    fast = mb.st_dp(*args, LIM, want_tables=False, n_s_max=N)
+    knob("MP_ST_GENERIC", 1)
+    gen = mb.st_dp(*args, LIM, want_tables=False, n_s_max=N)
+    knob("MP_ST_GENERIC", 2)
+    ref = mb.st_dp(*args, LIM, want_tables=False, n_s_max=N)
+    knob("MP_ST_GENERIC", -1)
+    torch.cuda.synchronize()
+    assert int(ref["path_len"].min()) >= 2
+    for name, o in (("library's choice", fast), ("every path", gen)):
+        assert torch.equal(o["path_s_ind"], ref["path_s_ind"]) and torch.equal(o["path_len"], ref["path_len"]), name
+
+
 def test_st_regions_pipeline_goldens():
     import torch
     from motion_planning_amd import batch as mb
